@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference's OWN embedded torch oracles.
+
+Runs ONLY in the build container (needs /root/reference).  The reference's test
+files cannot be imported (top-level ``import sgl_kernel`` + work at import time),
+so the pure-torch oracle functions are lifted out of the files with ``ast`` and
+executed here on seeded inputs.  What is committed under tests/golden/ is data:
+inputs (or the seed recipe + an input checksum for large cases) and the outputs
+the reference's oracle produced.  No reference source text is stored.
+
+    python tests/golden/make_golden.py            # regenerate everything
+    python tests/golden/make_golden.py moe_fp8    # one family
+
+Families -> reference oracle used
+  moe_fp8   native_fused_moe + scaled_weight   /root/reference/test_moe_fp8_ext.py:22-25,70-91
+            (masked -1 ids variant)            /root/reference/test_moe_offloading_cpu.py:29-52
+  moe_int8  torch_w8a8_per_column_moe          /root/reference/test_moe_int8.py:16-94
+  moe_bf16  torch_naive_moe                    /root/reference/test_moe.py:22-54
+  topk      grouped_topk_native / biased       /root/reference/test_grouped_topk.py:9-39,
+                                               /root/reference/test_biased_grouped_topk.py:9-47
+  norm      forward_native (rmsnorm)           /root/reference/test_norm.py:15-33
+  act       silu_and_mul                       /root/reference/test_activation.py:14-16
+  gemm      native_w8a8_per_token_matmul etc.  /root/reference/test_gemm_int8.py:14-47,
+                                               /root/reference/test_gemm_fp8.py:22-49
+  attn      _run_sdpa_forward_extend/decode    /root/reference/test_extend.py:10-76,
+                                               /root/reference/test_mla.py:12-66
+"""
+import ast
+import hashlib
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+from safetensors.torch import save_file
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def lift(path, names, extra_globals=None):
+    """Compile the named top-level FunctionDefs of a reference file into a fresh namespace."""
+    src = open(os.path.join(REF, path)).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in keep}
+    if missing:
+        raise RuntimeError(f"{path}: functions not found: {missing}")
+    mod = ast.Module(body=keep, type_ignores=[])
+    ns = {"torch": torch, "F": F, "math": math}
+    if extra_globals:
+        ns.update(extra_globals)
+    exec(compile(mod, os.path.join(REF, path), "exec"), ns)
+    return ns
+
+
+def checksum(*tensors):
+    h = hashlib.sha256()
+    for t in tensors:
+        t = t.contiguous()
+        if t.dtype in (torch.float8_e4m3fn, torch.bfloat16):
+            t = t.view(torch.uint8 if t.dtype == torch.float8_e4m3fn else torch.int16)
+        h.update(t.numpy().tobytes())
+    return h.hexdigest()
+
+
+def as_saveable(d):
+    out = {}
+    for k, v in d.items():
+        v = v.contiguous()
+        if v.dtype == torch.float8_e4m3fn:
+            out[k + "__fp8"] = v.view(torch.uint8)
+        else:
+            out[k] = v
+    return out
+
+
+def save(name, tensors, meta):
+    meta = {k: str(v) for k, v in meta.items()}
+    save_file(as_saveable(tensors), os.path.join(OUT, name + ".safetensors"), metadata=meta)
+    sz = os.path.getsize(os.path.join(OUT, name + ".safetensors"))
+    print(f"  wrote {name}.safetensors ({sz/1024:.0f} KiB) meta={meta}")
+
+
+# --------------------------------------------------------------------------------------
+# input recipes (shared with tests/ via tests/recipes.py — keep in sync: this file imports it)
+# --------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(OUT, ".."))
+import recipes  # noqa: E402
+
+
+def gen_moe_fp8():
+    for case in recipes.MOE_FP8_CASES:
+        name, M, N, K, E, topk, bn, bk, masked, seed, full = case
+        inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed)
+        if masked:
+            ns = lift("test_moe_offloading_cpu.py", ["SiluAndMul", "scaled_weight", "native_fused_moe"],
+                      {"BLOCK_N": bn, "BLOCK_K": bk})
+        else:
+            ns = lift("test_moe_fp8_ext.py", ["SiluAndMul", "scaled_weight", "native_fused_moe"],
+                      {"BLOCK_N": bn, "BLOCK_K": bk})
+        w1_scaled = ns["scaled_weight"](inp["w1"], inp["w1s"])
+        w2_scaled = ns["scaled_weight"](inp["w2"], inp["w2s"])
+        ids = inp["topk_ids"] if masked else inp["topk_ids"].to(torch.int64)
+        ref = ns["native_fused_moe"](inp["a"], w1_scaled, w2_scaled, inp["topk_weight"], ids, topk)
+        ref = ref.float()
+        meta = dict(M=inp["a"].shape[0], N=N, K=K, E=E, topk=topk, block_n=bn, block_k=bk, masked=int(masked),
+                    seed=seed, full=int(full),
+                    input_sha256=checksum(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"],
+                                          inp["topk_weight"], inp["topk_ids"]))
+        tensors = {"ref_out_f32": ref}
+        if full:
+            tensors.update(inp)
+        save("moe_fp8_" + name, tensors, meta)
+
+
+def gen_moe_int8():
+    ns = lift("test_moe_int8.py", ["silu_and_mul", "per_token_quant_int8", "native_w8a8_per_token_matmul",
+                                   "torch_w8a8_per_column_moe"])
+    for case in recipes.MOE_INT8_CASES:
+        name, M, N, K, E, topk, seed, full = case
+        inp = recipes.moe_int8_inputs(M, N, K, E, topk, seed)
+        ref = ns["torch_w8a8_per_column_moe"](inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"],
+                                              inp["topk_weight"], inp["topk_ids"].to(torch.int64), topk)
+        meta = dict(M=M, N=N, K=K, E=E, topk=topk, seed=seed, full=int(full),
+                    input_sha256=checksum(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"],
+                                          inp["topk_weight"], inp["topk_ids"]))
+        tensors = {"ref_out": ref}
+        if full:
+            tensors.update(inp)
+        save("moe_int8_" + name, tensors, meta)
+
+
+def gen_moe_bf16():
+    ns = lift("test_moe.py", ["SiluAndMul", "torch_naive_moe"])
+    for case in recipes.MOE_BF16_CASES:
+        name, M, N, K, E, topk, renorm, seed, full = case
+        inp = recipes.moe_bf16_inputs(M, N, K, E, topk, seed)
+        ref = ns["torch_naive_moe"](inp["a"], inp["w1"], inp["w2"], inp["score"], topk, renorm)
+        meta = dict(M=M, N=N, K=K, E=E, topk=topk, renorm=int(renorm), seed=seed, full=int(full),
+                    input_sha256=checksum(inp["a"], inp["w1"], inp["w2"], inp["score"]))
+        tensors = {"ref_out": ref}
+        if full:
+            tensors.update(inp)
+        save("moe_bf16_" + name, tensors, meta)
+
+
+def gen_topk():
+    ns = lift("test_grouped_topk.py", ["grouped_topk_native"])
+    nsb = lift("test_biased_grouped_topk.py", ["biased_grouped_topk"])
+    for case in recipes.TOPK_CASES:
+        name, M, E, G, topk, topk_group, renorm, biased, seed = case
+        inp = recipes.topk_inputs(M, E, biased, seed)
+        if biased:
+            w, ids = nsb["biased_grouped_topk"](inp["hidden"].float(), inp["gating"].float(), inp["bias"].float(),
+                                                topk, renorm, G, topk_group)
+        else:
+            w, ids = ns["grouped_topk_native"](inp["hidden"].float(), inp["gating"].float(), topk, renorm, G, topk_group)
+        tensors = dict(inp)
+        tensors["ref_w"] = w.float()
+        tensors["ref_ids"] = ids.to(torch.int32)
+        save("topk_" + name, tensors, dict(M=M, E=E, G=G, topk=topk, topk_group=topk_group, renorm=int(renorm),
+                                            biased=int(biased), seed=seed))
+
+
+FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(FAMILIES)
+    for fam in which:
+        print(f"[{fam}]")
+        FAMILIES[fam]()

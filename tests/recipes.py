@@ -1,0 +1,132 @@
+"""Seeded input recipes shared by tests/golden/make_golden.py and the parity tests.
+
+Each recipe mirrors how the reference harness builds its inputs (cited per function) but is
+written for this repo; torch's CPU generator is deterministic for a fixed torch build, and every
+golden file also stores a sha256 of the inputs it was generated from so drift is detected rather
+than silently compared.
+"""
+import math
+
+import torch
+
+FP8_MAX, FP8_MIN = 400.0, -400.0          # reference clamps to +-400 before the e4m3 cast
+SCALE_FACTOR = 1e-3                        # block-scale magnitude used by the reference tests
+
+# name, M, N, K, E, topk, block_n, block_k, masked(-1 ids), seed, store_full_inputs
+MOE_FP8_CASES = [
+    # shapes of /root/reference/test_moe_fp8_ext.py:122-124 (block [64,128])
+    ("m2_n128_k128_e8_t4", 2, 128, 128, 8, 4, 64, 128, False, 1111, True),
+    ("m121_n512_k1024_e8_t2", 121, 512, 1024, 8, 2, 64, 128, False, 1112, False),
+    ("m1212_n512_k1024_e8_t2", 1212, 512, 1024, 8, 2, 64, 128, False, 1113, False),
+    # shape of /root/reference/test_moe_offloading_cpu.py:145 (block [128,128], -1 padded ids)
+    ("masked_m14_n128_k128_e8_t8", 14, 128, 128, 8, 8, 128, 128, True, 1114, True),
+    ("masked_m300_n256_k512_e16_t8", 300, 256, 512, 16, 8, 128, 128, True, 1115, False),
+    # Qwen3-30B-A3B expert dims (models/Qwen3-VL-30B-A3B-Instruct/config.json:16,22,25,26), few experts
+    ("qwen3dims_m96_e8_t8", 96, 768, 2048, 8, 8, 128, 128, False, 1116, False),
+    # ragged / edge: one token, topk == E, every expert hit
+    ("m1_n128_k256_e4_t4", 1, 128, 256, 4, 4, 128, 128, False, 1117, True),
+]
+
+# name, M, N, K, E, topk, seed, full      (/root/reference/test_moe_int8.py:139-141)
+MOE_INT8_CASES = [
+    ("m1_n128_k256_e8_t2", 1, 128, 256, 8, 2, 2111, True),
+    ("m39_n1280_k1024_e8_t3", 39, 1280, 1024, 8, 3, 2112, False),
+    ("m257_n256_k512_e8_t3", 257, 256, 512, 8, 3, 2113, False),
+]
+
+# name, M, N, K, E, topk, renormalize, seed, full   (/root/reference/test_moe.py:109-112)
+MOE_BF16_CASES = [
+    ("m4_n32_k32_e4_t2", 4, 32, 32, 4, 2, False, 3111, True),
+    ("m2_n128_k32_e4_t2_renorm", 2, 128, 32, 4, 2, True, 3112, True),
+    ("m224_n256_k1056_e8_t2_renorm", 224, 256, 1024 + 32, 8, 2, True, 3113, False),
+]
+
+# name, M, E, G, topk, topk_group, renormalize, biased, seed
+# (/root/reference/test_grouped_topk.py:80-88, test_biased_grouped_topk.py:94-95)
+TOPK_CASES = [
+    ("m123_e8_g2_k2_tg1_r1", 123, 8, 2, 2, 1, True, False, 111),
+    ("m123_e16_g4_k3_tg2_r0", 123, 16, 4, 3, 2, False, False, 112),
+    ("m123_e32_g4_k3_tg2_r1", 123, 32, 4, 3, 2, True, False, 113),
+    ("m123_e64_g1_k6_tg1_r0", 123, 64, 1, 6, 1, False, False, 114),
+    ("m123_e256_g8_k4_tg8_r1", 123, 256, 8, 4, 8, True, False, 115),
+    ("m123_e160_g8_k6_tg2_r0", 123, 160, 8, 6, 2, False, False, 116),
+    ("m123_e128_g1_k8_tg1_r1", 123, 128, 1, 8, 1, True, False, 117),   # Qwen3 routing: 128 experts top-8
+    ("biased_m122_e256_g8_k8_tg2_r1", 122, 256, 8, 8, 2, True, True, 118),
+    ("biased_m122_e256_g8_k8_tg2_r0", 122, 256, 8, 8, 2, False, True, 119),
+]
+
+
+def _gen(seed):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return g
+
+
+def routing_softmax_topk(M, E, topk, g, dtype=torch.bfloat16):
+    """softmax(randn[M,E] in bf16, f32) -> torch.topk; /root/reference/test_moe_fp8_ext.py:110-112."""
+    score = torch.randn(M, E, generator=g).to(dtype)
+    score = torch.softmax(score, dim=-1, dtype=torch.float32)
+    w, ids = torch.topk(score, topk)
+    return w.contiguous(), ids.to(torch.int32).contiguous()
+
+
+def fp8_weight(shape, g):
+    """randn*400 clamped then cast to e4m3fn; /root/reference/test_moe_fp8_ext.py:98-102."""
+    return (torch.randn(*shape, generator=g) * FP8_MAX).clamp(min=FP8_MIN, max=FP8_MAX).to(torch.float8_e4m3fn)
+
+
+def moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed):
+    g = _gen(seed)
+    if masked:
+        # /root/reference/test_moe_offloading_cpu.py:57-74: random ids, keep with prob ratio, pad -1,
+        # drop tokens whose slots are all -1, random (signed) routing weights
+        ids = torch.randint(0, E, (M, topk), generator=g, dtype=torch.int32)
+        ratio = max(topk / 128.0, 0.25)
+        keep = torch.rand(M, topk, generator=g) < ratio
+        ids[~keep] = -1
+        rows = ~(ids == -1).all(dim=1)
+        ids = ids[rows].contiguous()
+        M = ids.shape[0]
+        assert M > 0
+        topk_weight = torch.randn(M, topk, generator=g)
+    a = (torch.randn(M, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    w1 = fp8_weight((E, 2 * N, K), g)
+    w2 = fp8_weight((E, K, N), g)
+    w1s = torch.randn(E, 2 * N // bn, K // bk, generator=g) * SCALE_FACTOR
+    w2s = torch.randn(E, K // bn, N // bk, generator=g) * SCALE_FACTOR
+    if not masked:
+        topk_weight, ids = routing_softmax_topk(M, E, topk, g)
+    return dict(a=a, w1=w1, w2=w2, w1s=w1s, w2s=w2s, topk_weight=topk_weight, topk_ids=ids)
+
+
+def moe_int8_inputs(M, N, K, E, topk, seed):
+    """/root/reference/test_moe_int8.py:97-124."""
+    g = _gen(seed)
+    a = (torch.randn(M, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    w1 = (((torch.rand(E, 2 * N, K, generator=g) - 0.5) * 2) * 127).clamp(-128, 127).to(torch.int8)
+    w2 = (((torch.rand(E, K, N, generator=g) - 0.5) * 2) * 127).clamp(-128, 127).to(torch.int8)
+    w1s = torch.rand(E, 2 * N, generator=g) * 1e-2
+    w2s = torch.rand(E, K, generator=g) * 1e-2
+    topk_weight, ids = routing_softmax_topk(M, E, topk, g)
+    return dict(a=a, w1=w1, w2=w2, w1s=w1s, w2s=w2s, topk_weight=topk_weight, topk_ids=ids)
+
+
+def moe_bf16_inputs(M, N, K, E, topk, seed):
+    """/root/reference/test_moe.py:96-101."""
+    g = _gen(seed)
+    a = (torch.randn(M, K, generator=g) / 10).to(torch.bfloat16)
+    w1 = (torch.randn(E, 2 * N, K, generator=g) / 10).to(torch.bfloat16)
+    w2 = (torch.randn(E, K, N, generator=g) / 10).to(torch.bfloat16)
+    score = torch.randn(M, E, generator=g).to(torch.bfloat16)
+    return dict(a=a, w1=w1, w2=w2, score=score)
+
+
+def topk_inputs(M, E, biased, seed):
+    """/root/reference/test_grouped_topk.py:44-46, test_biased_grouped_topk.py:53-55."""
+    g = _gen(seed)
+    hidden = torch.randn(M, 100, generator=g).to(torch.bfloat16)
+    gating = (torch.randn(M, E, generator=g) * 2 * M).to(torch.bfloat16)
+    d = dict(hidden=hidden, gating=gating)
+    if biased:
+        d["bias"] = torch.randn(E, generator=g).to(torch.bfloat16)
+    return d

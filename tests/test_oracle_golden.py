@@ -1,0 +1,91 @@
+"""Pins the oracle (torch + plain-C restatements) against golden vectors produced by the
+reference's own embedded oracles (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import pytest
+import torch
+
+import recipes
+from conftest import load_golden
+from oracle import c_oracle, moe
+
+
+def _sha(*ts):
+    h = hashlib.sha256()
+    for t in ts:
+        t = t.contiguous()
+        if t.dtype == torch.float8_e4m3fn:
+            t = t.view(torch.uint8)
+        elif t.dtype == torch.bfloat16:
+            t = t.view(torch.int16)
+        h.update(t.numpy().tobytes())
+    return h.hexdigest()
+
+
+def fp8_case_inputs(case):
+    name, M, N, K, E, topk, bn, bk, masked, seed, full = case
+    g, meta = load_golden("moe_fp8_" + name)
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed)
+    assert _sha(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["topk_weight"], inp["topk_ids"]) \
+        == meta["input_sha256"], "input recipe drifted from the golden file"
+    if full:  # stored inputs must equal the regenerated ones bit for bit
+        for k in ("a", "w1", "w2", "w1s", "w2s", "topk_weight", "topk_ids"):
+            x, y = g[k], inp[k]
+            if x.dtype == torch.float8_e4m3fn:
+                x, y = x.view(torch.uint8), y.view(torch.uint8)
+            assert torch.equal(x, y), k
+    return inp, g["ref_out_f32"], (bn, bk)
+
+
+def _check_fp32_or_bf16(out, ref, masked):
+    if masked:
+        # /root/reference/test_moe_offloading_cpu.py:52 rounds its oracle's result to bf16 (.to(old_dtype)):
+        # equal after the same rounding, up to one bf16 ulp where the fp32 sums differ in the last bits
+        torch.testing.assert_close(out.bfloat16().float(), ref, rtol=2 ** -7, atol=1e-6)
+    else:
+        # same fp32 math, different summation grouping only
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", recipes.MOE_FP8_CASES, ids=lambda c: c[0])
+def test_torch_oracle_fp8_matches_reference(case):
+    inp, ref, block = fp8_case_inputs(case)
+    out = moe.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
+                                inp["topk_weight"], inp["topk_ids"])
+    _check_fp32_or_bf16(out, ref, case[8])
+
+
+@pytest.mark.parametrize("case", recipes.MOE_FP8_CASES, ids=lambda c: c[0])
+def test_c_oracle_fp8_matches_reference(case):
+    inp, ref, block = fp8_case_inputs(case)
+    out = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
+                                     inp["topk_weight"], inp["topk_ids"])
+    _check_fp32_or_bf16(out, ref, case[8])
+    # and it passes the reference's own predicate (utils.compare, bf16 tolerance)
+    assert moe.allclose_ref(ref.bfloat16(), out.bfloat16())
+
+
+@pytest.mark.parametrize("case", recipes.MOE_INT8_CASES, ids=lambda c: c[0])
+def test_torch_oracle_int8_matches_reference(case):
+    name, M, N, K, E, topk, seed, full = case
+    g, meta = load_golden("moe_int8_" + name)
+    inp = recipes.moe_int8_inputs(M, N, K, E, topk, seed)
+    assert _sha(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["topk_weight"], inp["topk_ids"]) \
+        == meta["input_sha256"]
+    out = moe.fused_experts_int8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"],
+                                 inp["topk_weight"], inp["topk_ids"])
+    ref = g["ref_out"].float()          # reference returns bf16 (.to(a.dtype))
+    torch.testing.assert_close(out.bfloat16().float(), ref, rtol=1e-2, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", recipes.MOE_BF16_CASES, ids=lambda c: c[0])
+def test_torch_oracle_bf16_matches_reference(case):
+    name, M, N, K, E, topk, renorm, seed, full = case
+    g, meta = load_golden("moe_bf16_" + name)
+    inp = recipes.moe_bf16_inputs(M, N, K, E, topk, seed)
+    assert _sha(inp["a"], inp["w1"], inp["w2"], inp["score"]) == meta["input_sha256"]
+    w, ids = moe.softmax_topk(inp["score"], topk, renorm)
+    out = moe.fused_experts_f32(inp["a"], inp["w1"].float(), inp["w2"].float(), w, ids)
+    # the reference's bf16 oracle (test_moe.py:22-54) computes in bf16 end to end; ours in fp32:
+    # they agree to the reference's own bf16 tolerance
+    assert moe.allclose_ref(g["ref_out"], out.bfloat16())
