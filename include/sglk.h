@@ -1,0 +1,120 @@
+/*
+ * sglk — C-ABI of the MI355X (gfx950) sgl_kernel hot path.
+ *
+ * This is the drop-in boundary.  The reference harness reaches its kernels through
+ * `torch.ops.sgl_kernel.<op>` (e.g. /root/reference/bench_moe.py:5-6); the library behind those ops is the
+ * absent third-party CPU build of sgl_kernel.  Every entry point below is what that operator's binding
+ * would call for this path: plain pointers, sizes, strides and a HIP stream — no torch types.
+ * The Python package `sgl_kernel` (sgl-cpu-tests_amd/sgl_kernel) registers the reference's operator
+ * signatures with torch.library and forwards to these symbols through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host; the caller owns all memory, including the
+ *     workspace (query the size with the matching *_workspace_bytes function; 256-byte aligned);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
+ *     synchronises, allocates or frees (hipGraph-capture safe);
+ *   - return value: 0 on success, negative SGLK_ERR_* otherwise; sglk_last_error() gives a thread-local
+ *     message.  Shape/divisibility violations are rejected before anything is launched;
+ *   - bf16 = uint16_t bit pattern, fp8 = OCP e4m3fn byte, strides in ELEMENTS.
+ */
+#ifndef SGLK_H_
+#define SGLK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGLK_VERSION 100 /* 0.1.0 */
+
+enum {
+    SGLK_OK = 0,
+    SGLK_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unsupported flag) */
+    SGLK_ERR_SHAPE = -2,       /* shape / divisibility contract violated */
+    SGLK_ERR_WORKSPACE = -3,   /* workspace too small */
+    SGLK_ERR_LAUNCH = -4       /* HIP reported a launch error */
+};
+
+/* weight element types accepted by the pack / GEMM entry points */
+enum {
+    SGLK_W_BF16 = 0,
+    SGLK_W_FP8_E4M3 = 1,
+    SGLK_W_INT8 = 2
+};
+
+int sglk_version(void);
+const char* sglk_last_error(void);
+/* number of compute units / name of device `dev` (host-side query used by the bench for roofline peaks) */
+int sglk_device_cu_count(int dev);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * convert_weight_packed        replaces torch.ops.sgl_kernel.convert_weight_packed
+ *                              (/root/reference/bench_moe.py:26-27,43-44; test_moe_fp8_ext.py:114-115)
+ * Re-tiles `batch` row-major matrices [rows][cols] into the MFMA-operand tile order the GEMM kernels stream
+ * (DESIGN.md §Packed weight layout).  Output has the same byte size, dtype and shape as the input, so it
+ * stays an ordinary clonable tensor exactly like the reference's packed weights (bench_moe.py:53-58).
+ * Requirements: rows % 16 == 0; cols % 64 == 0 (fp8/int8) or cols % 32 == 0 (bf16).
+ * --------------------------------------------------------------------------------------------------------- */
+int sglk_pack_weight(const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int wtype,
+                     void* stream);
+/* inverse of sglk_pack_weight (used by tests: pack -> unpack must be the identity) */
+int sglk_unpack_weight(const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int wtype,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * fused_experts               replaces torch.ops.sgl_kernel.fused_experts_cpu
+ *     14-arg form /root/reference/bench_moe.py:113-130, test_moe_fp8_ext.py:118,
+ *     test_moe_offloading_cpu.py:103-117; 13-arg form /root/reference/test_moe.py:79-92.
+ *
+ *   out[m] = sum_j topk_weights[m,j] * ( silu(x_m W1g[e]^T) * (x_m W1u[e]^T) ) W2[e]^T ,  e = topk_ids[m,j]
+ *   slots with topk_ids outside [0,E) (the reference's -1 padding) contribute nothing.
+ *
+ * hidden  [M][K] bf16, row stride hidden_stride        out [M][K] bf16 (may alias hidden: `inplace`)
+ * w1      [E][2N][K]  rows [0,N) gate, [N,2N) up       w2  [E][K][N]
+ * wtype   SGLK_W_FP8_E4M3: W8A16, w*_scale f32 [E][ceil(rows/block_n)][ceil(cols/block_k)], block_k == 128
+ *         SGLK_W_BF16    : scales ignored
+ *         SGLK_W_INT8    : W8A8 dynamic per-token activation quant, w1_scale [E][2N], w2_scale [E][K]
+ * packed  != 0: weights are in sglk_pack_weight order (reference `is_vnni=True`); 0: plain row-major
+ * topk_weights [M][topk] f32, topk_ids [M][topk] i32
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* hidden;
+    int64_t hidden_stride;
+    void* out;
+    int64_t out_stride;
+    const void* w1;
+    const void* w2;
+    const float* w1_scale;
+    const float* w2_scale;
+    const float* topk_weights;
+    const int32_t* topk_ids;
+    int32_t M, N, K, E, topk;
+    int32_t wtype;
+    int32_t packed;
+    int32_t block_n, block_k;
+    void* workspace;
+    size_t workspace_bytes;
+} sglk_fused_experts_args;
+
+size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
+int sglk_fused_experts(const sglk_fused_experts_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stages of fused_experts exposed for tests and profiling (same kernels the fused call launches).
+ * moe_align: counting sort of the M*topk slots by expert (ids outside [0,E) dropped), stable in slot order.
+ *   sorted_slot [M*topk] i32   slot = m*topk + j, grouped by expert
+ *   expert_off  [E+1]    i32   exclusive prefix of per-expert counts
+ *   tile_info   [max_tiles][4] i32  {expert, first position, rows (<= tile_m), 0}; num_tiles[0] = count
+ * --------------------------------------------------------------------------------------------------------- */
+size_t sglk_moe_align_workspace_bytes(int32_t M, int32_t E, int32_t topk);
+int32_t sglk_moe_max_tiles(int32_t M, int32_t E, int32_t topk, int32_t tile_m);
+int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
+                   int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGLK_H_ */

@@ -1,0 +1,133 @@
+// fused_experts: the C-ABI entry point that chains align -> GEMM-1(+SiLU*mul) -> GEMM-2(*topk_w) -> combine.
+// Operator contract: /root/reference/bench_moe.py:113-130 (14-arg), /root/reference/test_moe.py:79-92 (13-arg).
+#include "moe_internal.h"
+
+using namespace sglk;
+
+namespace {
+
+struct Workspace {
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, total;
+};
+
+Workspace plan_workspace(int M, int N, int K, int E, int topk) {
+    Workspace w{};
+    const int64_t S = (int64_t)M * topk;
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes ? bytes : 1, 256);
+        return o;
+    };
+    w.align_ws = take(sglk_moe_align_workspace_bytes(M, E, topk));
+    w.sorted_slot = take((size_t)S * sizeof(int));
+    w.expert_off = take((size_t)(E + 1) * sizeof(int));
+    w.tile_info = take((size_t)max_tiles * 4 * sizeof(int));
+    w.num_tiles = take(sizeof(int));
+    w.ic1 = take((size_t)S * N * 2);
+    w.ic2 = take((size_t)S * K * 2);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
+                                                     int32_t wtype) {
+    (void)wtype;
+    if (M < 0 || N <= 0 || K <= 0 || E <= 0 || topk <= 0) return 0;
+    return plan_workspace(M, N, K, E, topk).total;
+}
+
+extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "fused_experts: null args");
+    const int M = a->M, N = a->N, K = a->K, E = a->E, topk = a->topk;
+    SGLK_REQUIRE(M >= 0 && N > 0 && K > 0 && E > 0 && topk > 0, SGLK_ERR_INVALID,
+                 "fused_experts: bad sizes M=%d N=%d K=%d E=%d topk=%d", M, N, K, E, topk);
+    SGLK_REQUIRE(a->w1 && a->w2 && a->workspace, SGLK_ERR_INVALID, "fused_experts: null pointer");
+    SGLK_REQUIRE(M == 0 || (a->hidden && a->out && a->topk_weights && a->topk_ids), SGLK_ERR_INVALID,
+                 "fused_experts: null pointer");
+    SGLK_REQUIRE(a->hidden_stride >= K && a->out_stride >= K, SGLK_ERR_INVALID, "fused_experts: row stride < K");
+    SGLK_REQUIRE((int64_t)M * topk * (int64_t)(K > N ? K : N) < (1ll << 40), SGLK_ERR_SHAPE, "fused_experts: too large");
+    hipStream_t s = (hipStream_t)stream;
+
+    if (a->wtype != SGLK_W_FP8_E4M3)
+        SGLK_FAIL(SGLK_ERR_INVALID, "fused_experts: weight type %d not built yet (fp8 W8A16 only)", a->wtype);
+    SGLK_REQUIRE(a->packed, SGLK_ERR_INVALID,
+                 "fused_experts: fp8 weights must be packed with sglk_pack_weight (is_vnni=True)");
+    SGLK_REQUIRE(a->w1_scale && a->w2_scale, SGLK_ERR_INVALID, "fused_experts: fp8 needs w1_scale and w2_scale");
+    SGLK_REQUIRE(a->block_k == 128, SGLK_ERR_SHAPE, "fused_experts: block_size[1] must be 128 (got %d)", a->block_k);
+    SGLK_REQUIRE(a->block_n > 0 && a->block_n % 16 == 0, SGLK_ERR_SHAPE,
+                 "fused_experts: block_size[0] must be a positive multiple of 16 (got %d)", a->block_n);
+    SGLK_REQUIRE(N % 128 == 0 && K % 128 == 0, SGLK_ERR_SHAPE,
+                 "fused_experts(fp8): N (%d) and K (%d) must be multiples of 128", N, K);
+    SGLK_REQUIRE((a->hidden_stride % 8) == 0 && (a->out_stride % 8) == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+                     ((uintptr_t)a->out % 16) == 0,
+                 SGLK_ERR_SHAPE, "fused_experts: hidden/out rows must be 16-byte aligned");
+
+    const Workspace w = plan_workspace(M, N, K, E, topk);
+    SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "fused_experts: workspace %zu < required %zu",
+                 a->workspace_bytes, w.total);
+    SGLK_REQUIRE(((uintptr_t)a->workspace % 256) == 0, SGLK_ERR_INVALID, "fused_experts: workspace must be 256-B aligned");
+    if (M == 0) return SGLK_OK;
+
+    unsigned char* ws = (unsigned char*)a->workspace;
+    int* sorted_slot = (int*)(ws + w.sorted_slot);
+    int* expert_off = (int*)(ws + w.expert_off);
+    int* tile_info = (int*)(ws + w.tile_info);
+    int* num_tiles = (int*)(ws + w.num_tiles);
+    uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
+    uint16_t* ic2 = (uint16_t*)(ws + w.ic2);
+
+    int rc = sglk_moe_align(a->topk_ids, M, E, topk, kTileM, sorted_slot, expert_off, tile_info, num_tiles,
+                            ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
+    if (rc != SGLK_OK) return rc;
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);
+
+    MoeGemmParams g1{};
+    g1.x = (const uint16_t*)a->hidden;
+    g1.x_stride = a->hidden_stride;
+    g1.sorted_slot = sorted_slot;
+    g1.topk = topk;
+    g1.w = (const uint8_t*)a->w1;
+    g1.w_expert_stride = (int64_t)2 * N * K;
+    g1.w_scale = a->w1_scale;
+    g1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+    g1.scale_cols = K / 128;
+    g1.block_n = a->block_n;
+    g1.C = K;
+    g1.n_half = N;
+    g1.tile_info = (const int4*)tile_info;
+    g1.num_tiles = num_tiles;
+    g1.n_tiles = N / 64;
+    g1.out = ic1;
+    g1.out_stride = N;
+    g1.topk_weights = nullptr;
+    rc = launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
+    if (rc != SGLK_OK) return rc;
+
+    MoeGemmParams g2{};
+    g2.x = ic1;
+    g2.x_stride = N;
+    g2.sorted_slot = sorted_slot;
+    g2.topk = topk;
+    g2.w = (const uint8_t*)a->w2;
+    g2.w_expert_stride = (int64_t)K * N;
+    g2.w_scale = a->w2_scale;
+    g2.scale_rows = (int)ceil_div(K, a->block_n);
+    g2.scale_cols = N / 128;
+    g2.block_n = a->block_n;
+    g2.C = N;
+    g2.n_half = 0;
+    g2.tile_info = (const int4*)tile_info;
+    g2.num_tiles = num_tiles;
+    g2.n_tiles = K / 128;
+    g2.out = ic2;
+    g2.out_stride = K;
+    g2.topk_weights = a->topk_weights;
+    rc = launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
+    if (rc != SGLK_OK) return rc;
+
+    return launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
+}

@@ -1,0 +1,167 @@
+// moe_align: stable counting sort of the M*topk routing slots by expert + the m-tile table the grouped GEMMs walk.
+//
+// Replaces the (unobservable) sort/align stage inside the reference's fused_experts_cpu
+// (/root/reference/bench_moe.py:113-130); the contract it must honour is the oracle's:
+// slot s = m*topk + j belongs to expert topk_ids[s]; ids outside [0,E) are dropped
+// (/root/reference/test_moe_offloading_cpu.py:62-68).  Integer-only, bit-reproducible: inside an expert the
+// slots keep ascending slot order.
+//
+// Three launches, no host sync, no atomics on global memory:
+//   count   : one wave per 512-slot chunk, LDS histogram                  -> counts[chunk][E]
+//   scan    : one workgroup: per-expert running sum over chunks (in place -> chunk base), block scan over
+//             experts -> expert_off[E+1]; tile table {expert, first position, rows} for tile_m rows per tile
+//   scatter : one wave per chunk, rank inside the wave by ballot match, running LDS counters across rounds
+#include "sglk_common.h"
+
+namespace sglk {
+
+constexpr int kAlignChunk = 512;   // slots per (single-wave) workgroup
+constexpr int kMaxExperts = 1024;
+
+__global__ __launch_bounds__(64) void moe_count_kernel(const int* __restrict__ ids, int S, int E,
+                                                       int* __restrict__ counts) {
+    __shared__ int hist[kMaxExperts];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < E; e += 64) hist[e] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kAlignChunk;
+#pragma unroll
+    for (int r = 0; r < kAlignChunk / 64; ++r) {
+        const int s = base + r * 64 + lane;
+        if (s < S) {
+            const int e = ids[s];
+            if (e >= 0 && e < E) atomicAdd(&hist[e], 1);
+        }
+    }
+    __syncthreads();
+    for (int e = lane; e < E; e += 64) counts[(size_t)blockIdx.x * E + e] = hist[e];
+}
+
+__global__ __launch_bounds__(1024) void moe_scan_kernel(int* __restrict__ counts, int nchunk, int E, int tile_m,
+                                                        int max_tiles, int* __restrict__ expert_off,
+                                                        int* __restrict__ tile_info, int* __restrict__ num_tiles) {
+    __shared__ int cnt[kMaxExperts];
+    __shared__ int2 scan[2][kMaxExperts];   // {slots, tiles} inclusive scans, ping-pong
+    const int e = threadIdx.x;
+    int total = 0;
+    if (e < E) {
+        for (int c = 0; c < nchunk; ++c) {
+            const int t = counts[(size_t)c * E + e];
+            counts[(size_t)c * E + e] = total;   // becomes the chunk's base inside the expert
+            total += t;
+        }
+    }
+    cnt[e] = total;
+    scan[0][e] = make_int2(total, (total + tile_m - 1) / tile_m);
+    __syncthreads();
+    int cur = 0;
+    for (int d = 1; d < kMaxExperts; d <<= 1) {
+        int2 v = scan[cur][e];
+        if (e >= d) {
+            const int2 o = scan[cur][e - d];
+            v.x += o.x;
+            v.y += o.y;
+        }
+        scan[cur ^ 1][e] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const int2 incl = scan[cur][e];
+    if (e < E) {
+        const int off = incl.x - total;
+        expert_off[e] = off;
+        if (e == E - 1) {
+            expert_off[E] = incl.x;
+            num_tiles[0] = incl.y < max_tiles ? incl.y : max_tiles;
+        }
+        const int nt = (total + tile_m - 1) / tile_m;
+        int t0 = incl.y - nt;
+        for (int i = 0; i < nt && t0 + i < max_tiles; ++i) {
+            const int rows = total - i * tile_m < tile_m ? total - i * tile_m : tile_m;
+            reinterpret_cast<int4*>(tile_info)[t0 + i] = make_int4(e, off + i * tile_m, rows, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void moe_scatter_kernel(const int* __restrict__ ids, int S, int E, int nbits,
+                                                         const int* __restrict__ chunk_base,
+                                                         const int* __restrict__ expert_off,
+                                                         int* __restrict__ sorted_slot) {
+    __shared__ int run[kMaxExperts];
+    const int lane = threadIdx.x;
+    for (int e = lane; e < E; e += 64) run[e] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kAlignChunk;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int r = 0; r < kAlignChunk / 64; ++r) {
+        const int s = base + r * 64 + lane;
+        int e = (s < S) ? ids[s] : -1;
+        const bool valid = e >= 0 && e < E;
+        if (!valid) e = 0;
+        // lanes holding the same expert id (emulated match-any: one ballot per id bit)
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (e >> b) & 1;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const int rank = __popcll(same & lt_mask);
+        const int before = valid ? run[e] : 0;
+        __syncthreads();
+        if (valid && rank == 0) run[e] = before + __popcll(same);
+        __syncthreads();
+        if (valid) {
+            const int pos = expert_off[e] + chunk_base[(size_t)blockIdx.x * E + e] + before + rank;
+            sorted_slot[pos] = s;
+        }
+    }
+}
+
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" size_t sglk_moe_align_workspace_bytes(int32_t M, int32_t E, int32_t topk) {
+    if (M < 0 || E <= 0 || topk <= 0) return 0;
+    const int64_t S = (int64_t)M * topk;
+    const int64_t nchunk = ceil_div(S, kAlignChunk);
+    return align_up((size_t)(nchunk > 0 ? nchunk : 1) * E * sizeof(int), 256);
+}
+
+extern "C" int32_t sglk_moe_max_tiles(int32_t M, int32_t E, int32_t topk, int32_t tile_m) {
+    if (M <= 0 || E <= 0 || topk <= 0 || tile_m <= 0) return 0;
+    const int64_t S = (int64_t)M * topk;
+    // every expert can add at most one partial tile, and no more experts than slots can be hit
+    const int64_t partial = S < E ? S : E;
+    return (int32_t)(S / tile_m + partial);
+}
+
+extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
+                              int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    SGLK_REQUIRE(M >= 0 && E > 0 && topk > 0 && tile_m > 0, SGLK_ERR_INVALID, "moe_align: bad sizes M=%d E=%d topk=%d", M, E, topk);
+    SGLK_REQUIRE(E <= kMaxExperts, SGLK_ERR_SHAPE, "moe_align: at most %d experts supported (got %d)", kMaxExperts, E);
+    SGLK_REQUIRE((int64_t)M * topk < (1ll << 31), SGLK_ERR_SHAPE, "moe_align: M*topk overflows int32");
+    SGLK_REQUIRE(expert_off && tile_info && num_tiles && workspace, SGLK_ERR_INVALID, "moe_align: null pointer");
+    SGLK_REQUIRE(M == 0 || (topk_ids && sorted_slot), SGLK_ERR_INVALID, "moe_align: null pointer");
+    SGLK_REQUIRE(workspace_bytes >= sglk_moe_align_workspace_bytes(M, E, topk), SGLK_ERR_WORKSPACE,
+                 "moe_align: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = M * topk;
+    const int nchunk = (int)ceil_div(S, kAlignChunk);
+    int* counts = (int*)workspace;
+    int nbits = 0;
+    while ((1 << nbits) < E) ++nbits;
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
+    if (nchunk > 0) {
+        hipLaunchKernelGGL(moe_count_kernel, dim3(nchunk), dim3(64), 0, s, topk_ids, S, E, counts);
+    }
+    hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(kMaxExperts), 0, s, counts, nchunk, E, tile_m, max_tiles,
+                       expert_off, tile_info, num_tiles);
+    if (nchunk > 0) {
+        hipLaunchKernelGGL(moe_scatter_kernel, dim3(nchunk), dim3(64), 0, s, topk_ids, S, E, nbits, counts,
+                           expert_off, sorted_slot);
+    }
+    SGLK_CHECK_LAUNCH("moe_align");
+    return SGLK_OK;
+}

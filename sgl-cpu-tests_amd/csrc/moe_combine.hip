@@ -1,0 +1,51 @@
+// Top-k reduce of fused_experts: out[m] = sum_j ic2[m*topk + j] over the valid slots, in ascending j, fp32,
+// one final bf16 rounding (the routing weight was already applied in the GEMM-2 epilogue).
+// Oracle: /root/reference/test_moe_fp8_ext.py:89-91.  Fixed summation order -> run-to-run identical bits.
+// HBM-bound: reads topk x K x 2 B and writes K x 2 B per token, 16-byte accesses.
+#include "moe_internal.h"
+
+namespace sglk {
+
+__global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __restrict__ ic2,
+                                                          const int32_t* __restrict__ topk_ids,
+                                                          uint16_t* __restrict__ out, int64_t out_stride, int M, int K,
+                                                          int E, int topk) {
+    const int chunks_per_row = K >> 3;   // 8 bf16 = 16 B per thread
+    const int64_t total = (int64_t)M * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks_per_row);
+        const int c = (int)(i - (int64_t)m * chunks_per_row);
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < topk; ++j) {
+            const int e = topk_ids[(int64_t)m * topk + j];
+            if (e < 0 || e >= E) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(ic2 + ((int64_t)m * topk + j) * K + c * 8);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sum[2 * q] += __uint_as_float(w[q] << 16);
+                sum[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u);
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16x2(sum[0], sum[1]);
+        o.y = pack_bf16x2(sum[2], sum[3]);
+        o.z = pack_bf16x2(sum[4], sum[5]);
+        o.w = pack_bf16x2(sum[6], sum[7]);
+        *reinterpret_cast<uint4*>(out + (int64_t)m * out_stride + c * 8) = o;
+    }
+}
+
+int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
+                       int K, int E, int topk, hipStream_t stream) {
+    if (M == 0) return SGLK_OK;
+    const int64_t total = (int64_t)M * (K >> 3);
+    int64_t blocks = ceil_div(total, 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ic2, topk_ids, out, out_stride,
+                       M, K, E, topk);
+    SGLK_CHECK_LAUNCH("moe_combine");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

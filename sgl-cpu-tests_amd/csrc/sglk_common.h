@@ -1,0 +1,69 @@
+// Shared host/device helpers for the sglk HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sglk.h"
+
+namespace sglk {
+
+// ---- error plumbing ---------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define SGLK_FAIL(code, ...)          \
+    do {                              \
+        ::sglk::set_error(__VA_ARGS__); \
+        return (code);                \
+    } while (0)
+
+#define SGLK_REQUIRE(cond, code, ...) \
+    do {                              \
+        if (!(cond)) SGLK_FAIL(code, __VA_ARGS__); \
+    } while (0)
+
+#define SGLK_CHECK_LAUNCH(what)                                                          \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device-side vector types -------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+#define SGLK_DEV __device__ __forceinline__
+
+SGLK_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// round-to-nearest-even f32 -> bf16 bits (plain cast keeps NaN a NaN; hipcc emits v_cvt_pk_bf16_f32)
+SGLK_DEV unsigned short f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+SGLK_DEV unsigned pack_bf16x2(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+SGLK_DEV float silu_f32(float g) { return g * __frcp_rn(1.0f + __expf(-g)); }
+
+// 8 XCDs, blocks are dealt round-robin: give every XCD a contiguous range of logical ids (bijective for any n)
+SGLK_DEV int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+}  // namespace sglk

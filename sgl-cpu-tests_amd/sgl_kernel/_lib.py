@@ -1,0 +1,67 @@
+"""ctypes view of libsglk.so — the C-ABI declared in include/sglk.h.  No compute happens in Python."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsglk.so")
+
+W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2
+
+
+class FusedExpertsArgs(ctypes.Structure):
+    """Mirror of `sglk_fused_experts_args` (include/sglk.h)."""
+    _fields_ = [
+        ("hidden", ctypes.c_void_p), ("hidden_stride", ctypes.c_int64),
+        ("out", ctypes.c_void_p), ("out_stride", ctypes.c_int64),
+        ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p),
+        ("w1_scale", ctypes.c_void_p), ("w2_scale", ctypes.c_void_p),
+        ("topk_weights", ctypes.c_void_p), ("topk_ids", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("E", ctypes.c_int32),
+        ("topk", ctypes.c_int32), ("wtype", ctypes.c_int32), ("packed", ctypes.c_int32),
+        ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+# symbol -> (restype, argtypes); every symbol include/sglk.h declares must be listed here
+# (tests/test_cabi_symbols.py checks the two against each other)
+_SIGNATURES = {
+    "sglk_version": (ctypes.c_int, []),
+    "sglk_last_error": (ctypes.c_char_p, []),
+    "sglk_device_cu_count": (ctypes.c_int, [ctypes.c_int]),
+    "sglk_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "sglk_unpack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "sglk_fused_experts_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 6),
+    "sglk_fused_experts": (ctypes.c_int, [ctypes.POINTER(FusedExpertsArgs), ctypes.c_void_p]),
+    "sglk_moe_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),
+    "sglk_moe_max_tiles": (ctypes.c_int32, [ctypes.c_int32] * 4),
+    "sglk_moe_align": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Fails loudly when the HIP extension has not been built: there is NO fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"sgl_kernel: {LIB_PATH} is missing — build it with `python sgl-cpu-tests_amd/build.py` "
+                "(hipcc, gfx950). This package has no CPU or PyTorch fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().sglk_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"sgl_kernel::{what} failed ({rc}): {msg}")

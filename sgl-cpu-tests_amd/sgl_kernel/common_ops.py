@@ -1,0 +1,8 @@
+"""Legacy import style of the reference harness: `from sgl_kernel.common_ops import <op>`
+(/root/reference/test_gemm.py:2-3, /root/reference/test_moe_fp8.py:4-5).  Thin aliases of torch.ops.sgl_kernel."""
+import torch
+
+from . import _ops  # noqa: F401
+
+convert_weight_packed = torch.ops.sgl_kernel.convert_weight_packed
+fused_experts_cpu = torch.ops.sgl_kernel.fused_experts_cpu
