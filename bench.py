@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fp8 (W8A16) fused_experts at Qwen3-30B-A3B expert shapes on MI355X.
+
+Own counterpart of /root/reference/bench_moe.py:110-132 (same operator, same argument order, rotating over L
+weight/input clones), with the dims swapped to Qwen3-30B-A3B (K=2048, N=768, E=128, top-8:
+/root/reference/models/Qwen3-VL-30B-A3B-Instruct/config.json:16,22,25,26), HIP-event timing and warm-up.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tokens M_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N ...
+
+One "step" = one fused_experts call over one batch of synthetic tokens already resident in HBM.
+  N = 1 : all 128 experts on the GPU.
+  N > 1 : expert parallel (weak scaling: every rank brings its own `--tokens` tokens and owns E/N experts);
+          dispatch / combine by RCCL all-to-all (sgl_kernel/expert_parallel.py).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel = GEMM-1, timed by
+HIP events on its own stream inside the timed region) and, at N = 1, `cpu_baseline` (plain-C oracle on the host).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+K_HIDDEN, N_INTER, N_EXPERTS, TOPK = 2048, 768, 128, 8
+BLOCK = [128, 128]
+FLOP_PER_TOKEN = TOPK * 6 * N_INTER * K_HIDDEN          # 75,497,472
+GEMM1_FLOP_PER_TOKEN = TOPK * 2 * (2 * N_INTER) * K_HIDDEN   # 50,331,648: the dominant kernel's share
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF); W8A16 math runs on bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(M, E_local, dev, seed):
+    """Bounded test-style data (/root/reference/test_moe_fp8_ext.py:96-112): raw randn scales overflow under reuse."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    a = (torch.randn(M, K_HIDDEN, device=dev, generator=g) / K_HIDDEN ** 0.5).bfloat16()
+    w1 = (torch.randn(E_local, 2 * N_INTER, K_HIDDEN, device=dev, generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+    w2 = (torch.randn(E_local, K_HIDDEN, N_INTER, device=dev, generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+    w1s = torch.randn(E_local, 2 * N_INTER // BLOCK[0], K_HIDDEN // BLOCK[1], device=dev, generator=g) * 1e-3
+    w2s = torch.randn(E_local, K_HIDDEN // BLOCK[0], N_INTER // BLOCK[1], device=dev, generator=g) * 1e-3
+    score = torch.softmax(torch.randn(M, N_EXPERTS, device=dev, generator=g).bfloat16(), dim=-1, dtype=torch.float32)
+    tw, ids = torch.topk(score, TOPK)
+    return a, w1, w2, w1s, w2s, tw.contiguous(), ids.to(torch.int32).contiguous()
+
+
+def cpu_baseline(tokens):
+    """Plain-C oracle (oracle/c/moe_fp8_ref.c, OpenMP) on a bounded sample of the same workload, host cores."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(99)
+    a = (torch.randn(tokens, K_HIDDEN, generator=g) / K_HIDDEN ** 0.5).bfloat16()
+    w1 = torch.randint(0, 256, (N_EXPERTS, 2 * N_INTER, K_HIDDEN), dtype=torch.uint8, generator=g)
+    w2 = torch.randint(0, 256, (N_EXPERTS, K_HIDDEN, N_INTER), dtype=torch.uint8, generator=g)
+    # keep clear of the two NaN encodings so the sample is ordinary arithmetic
+    w1[(w1 & 0x7F) == 0x7F] = 0x38
+    w2[(w2 & 0x7F) == 0x7F] = 0x38
+    w1, w2 = w1.view(torch.float8_e4m3fn), w2.view(torch.float8_e4m3fn)
+    w1s = torch.randn(N_EXPERTS, 2 * N_INTER // BLOCK[0], K_HIDDEN // BLOCK[1], generator=g) * 1e-3
+    w2s = torch.randn(N_EXPERTS, K_HIDDEN // BLOCK[0], N_INTER // BLOCK[1], generator=g) * 1e-3
+    score = torch.softmax(torch.randn(tokens, N_EXPERTS, generator=g), dim=-1)
+    tw, ids = torch.topk(score, TOPK)
+    c_oracle.fused_experts_fp8(a[:8], w1, w2, w1s, w2s, BLOCK, tw[:8], ids[:8].to(torch.int32))  # page-in / warm
+    t0 = time.perf_counter()
+    c_oracle.fused_experts_fp8(a, w1, w2, w1s, w2s, BLOCK, tw, ids.to(torch.int32))
+    dt = time.perf_counter() - t0
+    return {"value": round(tokens * FLOP_PER_TOKEN / dt / 1e12, 5), "unit": "TFLOP/s",
+            "tokens_per_s": round(tokens / dt, 1), "cores": c_oracle.num_threads(), "kind": "port",
+            "sample": f"{tokens} tokens of the same workload (all 128 experts, fp8 block-scaled weights), "
+                      f"{dt:.1f} s wall, plain-C oracle with OpenMP (build's own restatement, not upstream sgl_kernel)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tokens", type=int, default=int(os.environ.get("SGLK_BENCH_TOKENS", 16384)),
+                    help="tokens per GPU per step (BASELINE.md evaluates the MFMA roofline at M = 16384)")
+    ap.add_argument("--cpu-tokens", type=int, default=int(os.environ.get("SGLK_BENCH_CPU_TOKENS", 32768)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+
+    import sgl_kernel
+    from sgl_kernel import _lib, _ops
+    ops = torch.ops.sgl_kernel
+    L = _lib.lib()
+
+    M = args.tokens
+    E_local = N_EXPERTS // world
+    LCLONES = 2   # rotate over clones like bench_moe.py:50-58; 2 x 604 MB at N=1 exceeds the 256 MiB Infinity Cache
+    a, w1, w2, w1s, w2s, tw, ids = make_inputs(M, E_local, dev, 1111 + rank)
+    w1p, w2p = ops.convert_weight_packed(w1), ops.convert_weight_packed(w2)
+    del w1, w2
+    inputs = [a.clone() for _ in range(LCLONES)]
+    w1ps = [w1p.clone() for _ in range(LCLONES)]
+    w2ps = [w2p.clone() for _ in range(LCLONES)]
+    del w1p, w2p
+
+    timer = L.sglk_stage_timer_create(args.steps * 8 + 64)
+    step_idx = [0]
+
+    def local_experts(h, w, local_ids):
+        i = step_idx[0] % LCLONES
+        return ops.fused_experts_cpu(h, w1ps[i], w2ps[i], w, local_ids, False, False, True, w1s, w2s, BLOCK,
+                                     None, None, True)
+
+    if world == 1:
+        def step():
+            i = step_idx[0] % LCLONES
+            out = ops.fused_experts_cpu(inputs[i], w1ps[i], w2ps[i], tw, ids, False, False, True, w1s, w2s, BLOCK,
+                                        None, None, True)
+            step_idx[0] += 1
+            return out
+    else:
+        from sgl_kernel.expert_parallel import ExpertParallelMoE
+        ep = ExpertParallelMoE(N_EXPERTS, local_experts)
+
+        def step():
+            out = ep(inputs[step_idx[0] % LCLONES], tw, ids)
+            step_idx[0] += 1
+            return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _ops.set_stage_timer(timer)
+    L.sglk_stage_timer_reset(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    _ops.set_stage_timer(None)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    ms = (ctypes.c_float * _lib.NUM_STAGES)()
+    calls = ctypes.c_int32(0)
+    _lib.check(L.sglk_stage_timer_read(timer, ms, ctypes.byref(calls)), "stage_timer_read")
+    stage_ms = {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}
+    # rows the local GEMM-1 launch processed per call (EP: received valid slots; = M*topk per rank on average)
+    gemm1_ms = float(ms[1])
+
+    if rank == 0:
+        total_tokens = M * world
+        ms_per_step = elapsed / args.steps * 1e3
+        tflops = total_tokens * FLOP_PER_TOKEN / (elapsed / args.steps) / 1e12
+        gemm1_tflops = M * GEMM1_FLOP_PER_TOKEN / (gemm1_ms * 1e-3) / 1e12 if gemm1_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("tokens") == M and tj.get("n_gpus", 1) == world:
+                    traffic = tj.get("gemm1_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "fused_experts_fp8_w8a16_tflops", "value": round(tflops, 2), "unit": "TFLOP/s",
+            "tokens_per_s": round(total_tokens / (elapsed / args.steps), 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"fused_experts fp8-w8a16 block[128,128], Qwen3-30B-A3B experts "
+                                   f"(K={K_HIDDEN}, N={N_INTER}, E={N_EXPERTS}, top-{TOPK}), {M} tokens per GPU per step, "
+                                   f"inplace=False, {LCLONES} rotating weight/input clones",
+                       "tokens_per_gpu": M, "experts_per_gpu": E_local,
+                       "parallelism": "single GPU" if world == 1 else f"ep{world} (RCCL all-to-all dispatch/combine)"},
+            "roofline": {"bound": "mfma", "kernel": "moe_gemm_fp8w_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
+                         "achieved": round(gemm1_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm1_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "launches": int(calls.value), "avg_launch_ms": round(gemm1_ms, 4),
+                         "algorithmic_flop_per_launch": M * GEMM1_FLOP_PER_TOKEN,
+                         "note": "W8A16: fp8 weights are converted exactly to bf16 in registers and multiplied on "
+                                 "bf16 MFMA, so the dense bf16 peak (2.5 PF) is the governing roof"},
+            "stage_ms": stage_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_tokens)
+            except Exception as e:  # the bench line must still be printed
+                line["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
+        print(json.dumps(line), flush=True)
+
+    L.sglk_stage_timer_destroy(timer)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,7 @@ typedef struct {
     int32_t block_n, block_k;
     void* workspace;
     size_t workspace_bytes;
+    void* stage_timer; /* optional sglk_stage_timer (NULL = off): records HIP events around every stage */
 } sglk_fused_experts_args;
 
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
@@ -113,6 +114,19 @@ int32_t sglk_moe_max_tiles(int32_t M, int32_t E, int32_t topk, int32_t tile_m);
 int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
                    int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Stage timer (measurement only): a pool of HIP events recorded on the caller's stream between the stages of
+ * fused_experts, so bench.py can report the average duration of each kernel of the timed region itself
+ * (roofline.achieved) without a profiler.  Stages: 0 align, 1 gemm1 (gate/up + SiLU*mul), 2 gemm2, 3 combine.
+ * create(max_calls) -> handle; pass it in args.stage_timer; read() synchronises on the last event and returns the
+ * per-stage mean in milliseconds over the calls recorded since the last reset.
+ * --------------------------------------------------------------------------------------------------------- */
+#define SGLK_NUM_STAGES 4
+void* sglk_stage_timer_create(int32_t max_calls);
+void sglk_stage_timer_destroy(void* timer);
+void sglk_stage_timer_reset(void* timer);
+int sglk_stage_timer_read(void* timer, float* mean_ms /* [SGLK_NUM_STAGES] host */, int32_t* calls /* host */);
 
 #ifdef __cplusplus
 }

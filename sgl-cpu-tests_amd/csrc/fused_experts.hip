@@ -2,9 +2,17 @@
 // Operator contract: /root/reference/bench_moe.py:113-130 (14-arg), /root/reference/test_moe.py:79-92 (13-arg).
 #include "moe_internal.h"
 
+#include <vector>
+
 using namespace sglk;
 
 namespace {
+
+struct StageTimer {
+    int max_calls = 0, calls = 0;
+    std::vector<hipEvent_t> ev;   // (SGLK_NUM_STAGES + 1) events per call
+    hipEvent_t at(int call, int i) { return ev[(size_t)call * (SGLK_NUM_STAGES + 1) + i]; }
+};
 
 struct Workspace {
     size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, total;
@@ -80,9 +88,17 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
     uint16_t* ic2 = (uint16_t*)(ws + w.ic2);
 
+    StageTimer* tm = (StageTimer*)a->stage_timer;
+    if (tm && tm->calls >= tm->max_calls) tm = nullptr;   // pool exhausted: stop recording
+    const int call = tm ? tm->calls++ : 0;
+    auto mark = [&](int i) {
+        if (tm) hipEventRecord(tm->at(call, i), s);
+    };
+    mark(0);
     int rc = sglk_moe_align(a->topk_ids, M, E, topk, kTileM, sorted_slot, expert_off, tile_info, num_tiles,
                             ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
     if (rc != SGLK_OK) return rc;
+    mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);
 
     MoeGemmParams g1{};
@@ -106,6 +122,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     g1.topk_weights = nullptr;
     rc = launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
     if (rc != SGLK_OK) return rc;
+    mark(2);
 
     MoeGemmParams g2{};
     g2.x = ic1;
@@ -128,6 +145,54 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     g2.topk_weights = a->topk_weights;
     rc = launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
     if (rc != SGLK_OK) return rc;
+    mark(3);
 
-    return launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
+    rc = launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
+    mark(4);
+    return rc;
+}
+
+extern "C" void* sglk_stage_timer_create(int32_t max_calls) {
+    if (max_calls <= 0) return nullptr;
+    StageTimer* t = new StageTimer();
+    t->max_calls = max_calls;
+    t->ev.resize((size_t)max_calls * (SGLK_NUM_STAGES + 1));
+    for (auto& e : t->ev) {
+        if (hipEventCreate(&e) != hipSuccess) {
+            set_error("stage_timer: hipEventCreate failed");
+            delete t;
+            return nullptr;
+        }
+    }
+    return t;
+}
+
+extern "C" void sglk_stage_timer_destroy(void* timer) {
+    StageTimer* t = (StageTimer*)timer;
+    if (!t) return;
+    for (auto& e : t->ev) hipEventDestroy(e);
+    delete t;
+}
+
+extern "C" void sglk_stage_timer_reset(void* timer) {
+    if (timer) ((StageTimer*)timer)->calls = 0;
+}
+
+extern "C" int sglk_stage_timer_read(void* timer, float* mean_ms, int32_t* calls) {
+    StageTimer* t = (StageTimer*)timer;
+    SGLK_REQUIRE(t && mean_ms && calls, SGLK_ERR_INVALID, "stage_timer_read: null pointer");
+    *calls = t->calls;
+    for (int i = 0; i < SGLK_NUM_STAGES; ++i) mean_ms[i] = 0.f;
+    if (t->calls == 0) return SGLK_OK;
+    if (hipEventSynchronize(t->at(t->calls - 1, SGLK_NUM_STAGES)) != hipSuccess)
+        SGLK_FAIL(SGLK_ERR_LAUNCH, "stage_timer_read: hipEventSynchronize failed");
+    for (int c = 0; c < t->calls; ++c)
+        for (int i = 0; i < SGLK_NUM_STAGES; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t->at(c, i), t->at(c, i + 1)) != hipSuccess)
+                SGLK_FAIL(SGLK_ERR_LAUNCH, "stage_timer_read: hipEventElapsedTime failed");
+            mean_ms[i] += ms;
+        }
+    for (int i = 0; i < SGLK_NUM_STAGES; ++i) mean_ms[i] /= (float)t->calls;
+    return SGLK_OK;
 }

@@ -20,6 +20,7 @@ class FusedExpertsArgs(ctypes.Structure):
         ("topk", ctypes.c_int32), ("wtype", ctypes.c_int32), ("packed", ctypes.c_int32),
         ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+        ("stage_timer", ctypes.c_void_p),
     ]
 
 
@@ -40,7 +41,14 @@ _SIGNATURES = {
     "sglk_moe_align": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "sglk_stage_timer_create": (ctypes.c_void_p, [ctypes.c_int32]),
+    "sglk_stage_timer_destroy": (None, [ctypes.c_void_p]),
+    "sglk_stage_timer_reset": (None, [ctypes.c_void_p]),
+    "sglk_stage_timer_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                              ctypes.POINTER(ctypes.c_int32)]),
 }
+NUM_STAGES = 4
+STAGE_NAMES = ("align", "gemm1_gate_up_silu", "gemm2_down", "combine")
 
 _lib = None
 

@@ -102,6 +102,15 @@ _DEF.define(
     "bool inplace, int moe_comp_method, Tensor? w1_scale, Tensor? w2_scale, "
     "int[]? block_size, Tensor? a1_scale, Tensor? a2_scale, bool is_vnni) -> Tensor")
 
+# measurement hook (bench.py): when set to a sglk_stage_timer handle, every fused_experts call records stage events
+_stage_timer = None
+
+
+def set_stage_timer(handle):
+    global _stage_timer
+    _stage_timer = handle
+
+
 # sglang.srt.layers.amx_utils.CPUQuantMethod values (shim in sgl-cpu-tests_amd/sglang)
 UNQUANT, INT8_W8A8, FP8_W8A16 = 0, 1, 2
 
@@ -160,7 +169,7 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
         topk_weights=topk_weights.data_ptr(), topk_ids=topk_ids.data_ptr(),
         M=M, N=N, K=K, E=E, topk=topk, wtype=wtype,
         packed=1 if (is_vnni and _pack_supported(2 * N, K, wdtype) and _pack_supported(K, N, wdtype)) else 0,
-        block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+        block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=_stage_timer)
     rc = L.sglk_fused_experts(ctypes.byref(args), _stream(hidden_states))
     _lib.check(rc, "fused_experts_cpu")
     if inplace and out is not hidden_states:
