@@ -2,6 +2,8 @@
 // Operator contract: /root/reference/bench_moe.py:113-130 (14-arg), /root/reference/test_moe.py:79-92 (13-arg).
 #include "moe_internal.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 using namespace sglk;
@@ -18,10 +20,25 @@ struct Workspace {
     size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, total;
 };
 
+// tile height of the grouped GEMMs: 256-row tiles once experts see enough rows to fill them, else 128
+int pick_tile_m(int M, int N, int K, int E, int topk) {
+    const char* force = getenv("SGLK_MOE_TILE_M");
+    const int64_t S = (int64_t)M * topk;
+    // the 256 kernel addresses its operands through 32-bit buffer offsets
+    const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && S * (int64_t)N * 2 < (1ll << 32) &&
+                       (int64_t)M * K * 2 < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32);
+    if (force) {
+        const int f = atoi(force);
+        if (f == 256 && ok256) return 256;
+        if (f == 128) return 128;
+    }
+    return (ok256 && S >= (int64_t)192 * E) ? 256 : kTileM;
+}
+
 Workspace plan_workspace(int M, int N, int K, int E, int topk) {
     Workspace w{};
     const int64_t S = (int64_t)M * topk;
-    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);   // 128-row tiles bound the table size
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -95,15 +112,17 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         if (tm) hipEventRecord(tm->at(call, i), s);
     };
     mark(0);
-    int rc = sglk_moe_align(a->topk_ids, M, E, topk, kTileM, sorted_slot, expert_off, tile_info, num_tiles,
+    const int tile_m = pick_tile_m(M, N, K, E, topk);
+    int rc = sglk_moe_align(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                             ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
     if (rc != SGLK_OK) return rc;
     mark(1);
-    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
     MoeGemmParams g1{};
     g1.x = (const uint16_t*)a->hidden;
     g1.x_stride = a->hidden_stride;
+    g1.x_bytes = (int64_t)M * a->hidden_stride * 2;
     g1.sorted_slot = sorted_slot;
     g1.topk = topk;
     g1.w = (const uint8_t*)a->w1;
@@ -116,17 +135,19 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     g1.n_half = N;
     g1.tile_info = (const int4*)tile_info;
     g1.num_tiles = num_tiles;
-    g1.n_tiles = N / 64;
+    g1.n_tiles = tile_m == 256 ? N / 128 : N / 64;
     g1.out = ic1;
     g1.out_stride = N;
     g1.topk_weights = nullptr;
-    rc = launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
+    rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s)
+                       : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
     if (rc != SGLK_OK) return rc;
     mark(2);
 
     MoeGemmParams g2{};
     g2.x = ic1;
     g2.x_stride = N;
+    g2.x_bytes = (int64_t)M * topk * N * 2;
     g2.sorted_slot = sorted_slot;
     g2.topk = topk;
     g2.w = (const uint8_t*)a->w2;
@@ -139,11 +160,12 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     g2.n_half = 0;
     g2.tile_info = (const int4*)tile_info;
     g2.num_tiles = num_tiles;
-    g2.n_tiles = K / 128;
+    g2.n_tiles = tile_m == 256 ? K / 256 : K / 128;
     g2.out = ic2;
     g2.out_stride = K;
     g2.topk_weights = a->topk_weights;
-    rc = launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
+    rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s)
+                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
     if (rc != SGLK_OK) return rc;
     mark(3);
 

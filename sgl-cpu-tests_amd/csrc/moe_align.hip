@@ -40,18 +40,43 @@ __global__ __launch_bounds__(64) void moe_count_kernel(const int* __restrict__ i
 __global__ __launch_bounds__(1024) void moe_scan_kernel(int* __restrict__ counts, int nchunk, int E, int tile_m,
                                                         int max_tiles, int* __restrict__ expert_off,
                                                         int* __restrict__ tile_info, int* __restrict__ num_tiles) {
+    __shared__ int part_sum[kMaxExperts];   // [part][expert], parts * E <= 1024
     __shared__ int cnt[kMaxExperts];
     __shared__ int2 scan[2][kMaxExperts];   // {slots, tiles} inclusive scans, ping-pong
-    const int e = threadIdx.x;
+    const int tid = threadIdx.x;
+    // `parts` threads share one expert's column of the [chunk][expert] table, each walking a contiguous chunk range
+    const int parts = kMaxExperts / E;
+    const int e_of = tid % E, part = tid / E;
+    const int per = (nchunk + parts - 1) / parts;
+    const int c0 = part * per, c1 = (c0 + per < nchunk) ? c0 + per : nchunk;
+    int local = 0;
+    if (part < parts) {
+#pragma unroll 4
+        for (int c = c0; c < c1; ++c) local += counts[(size_t)c * E + e_of];
+        part_sum[part * E + e_of] = local;
+    }
+    __syncthreads();
     int total = 0;
-    if (e < E) {
-        for (int c = 0; c < nchunk; ++c) {
-            const int t = counts[(size_t)c * E + e];
-            counts[(size_t)c * E + e] = total;   // becomes the chunk's base inside the expert
-            total += t;
+    if (part < parts) {
+        int base = 0;
+        for (int q = 0; q < parts; ++q) {
+            const int v = part_sum[q * E + e_of];
+            if (q < part) base += v;
+            total += v;
+        }
+        // second walk: counts[c][e] becomes the chunk's base inside the expert (exclusive running sum)
+        int run = base;
+#pragma unroll 4
+        for (int c = c0; c < c1; ++c) {
+            const int t = counts[(size_t)c * E + e_of];
+            counts[(size_t)c * E + e_of] = run;
+            run += t;
         }
     }
-    cnt[e] = total;
+    const int e = tid;
+    if (part == 0) cnt[e_of] = total;
+    __syncthreads();
+    total = (e < E) ? cnt[e] : 0;
     scan[0][e] = make_int2(total, (total + tile_m - 1) / tile_m);
     __syncthreads();
     int cur = 0;

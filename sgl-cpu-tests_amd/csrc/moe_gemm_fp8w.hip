@@ -55,10 +55,13 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_kernel(const MoeGemmPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wm = wave >> 1;
 
-    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    // the grid is sized for the worst case; only the first num_tiles*n_tiles blocks have work.  The XCD remap is
+    // taken over THAT count, so every XCD gets an equal contiguous share of the real tiles.
+    const int live = p.num_tiles[0] * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int L = xcd_remap(blockIdx.x, live);
     const int mtile = L / p.n_tiles;
     const int ntile = L - mtile * p.n_tiles;
-    if (mtile >= p.num_tiles[0]) return;
     const int4 ti = p.tile_info[mtile];
     const int e = __builtin_amdgcn_readfirstlane(ti.x);
     const int pos0 = __builtin_amdgcn_readfirstlane(ti.y);

@@ -11,6 +11,7 @@ enum { MODE_GATE_UP = 0, MODE_DOWN = 1 };
 struct MoeGemmParams {
     const uint16_t* x;            // activations, bf16 bits
     int64_t x_stride;             // elements per row
+    int64_t x_bytes;              // extent of x in bytes (buffer-descriptor range; < 4 GiB for the 256 kernel)
     const int* sorted_slot;       // [M*topk] slots grouped by expert (moe_align)
     int topk;
     const uint8_t* w;             // packed weights [E][R][C]
@@ -29,6 +30,8 @@ struct MoeGemmParams {
 };
 
 int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+// 256-token x 256-row tiles, 8 waves, 3-deep LDS-DMA ring (moe_gemm_fp8w_256.hip); tile table built with tile_m = 256
+int launch_moe_gemm_fp8w_256(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,

@@ -58,7 +58,10 @@ SGLK_DEV unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-SGLK_DEV float silu_f32(float g) { return g * __frcp_rn(1.0f + __expf(-g)); }
+// g * sigmoid(g) with the hardware exp2 / rcp (1 ulp each): far inside the bf16 rounding of the result
+SGLK_DEV float silu_f32(float g) {
+    return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));
+}
 
 // 8 XCDs, blocks are dealt round-robin: give every XCD a contiguous range of logical ids (bijective for any n)
 SGLK_DEV int xcd_remap(int bid, int nblocks) {

@@ -145,3 +145,27 @@ def test_cpu_tensors_are_staged_through_the_gpu(ops):
                                 inp["w1s"], inp["w2s"], [bn, bk], None, None, True)
     assert out.device.type == "cpu" and out.data_ptr() == a.data_ptr()
     check_close(out, g["ref_out_f32"], "cpu-staged")
+
+
+@pytest.mark.parametrize("tile_m", ["128", "256"])
+@pytest.mark.parametrize("block", [(128, 128), (64, 128)])
+def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
+    """Both grouped-GEMM tilings (128-row 2-stage, 256-row 3-deep ring) against the plain-C oracle; ragged expert
+    loads (rows per expert not a multiple of either tile), wide dynamic range of block scales incl. zero/negative."""
+    monkeypatch.setenv("SGLK_MOE_TILE_M", tile_m)
+    M, N, K, E, topk = 1531, 256, 512, 8, 4
+    bn, bk = block
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 9001)
+    g = torch.Generator().manual_seed(5)
+    # scales spanning 2^-12 .. 2^4 with random sign, one exact zero block, one power of two
+    inp["w1s"] = inp["w1s"].sign() * torch.exp2(torch.rand(inp["w1s"].shape, generator=g) * 16 - 12) * 1e-2
+    inp["w1s"][0, 0, 0] = 0.0
+    inp["w2s"][1, 0, 0] = 0.0
+    inp["w2s"][2, 1, 1] = 2.0 ** -9
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
+                                     inp["topk_weight"], inp["topk_ids"])
+    # bring the outputs into the O(1) range the reference's atol=1e-2 is meant for (its tests produce |out| <~ 2)
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    out, _ = run_fp8(ops, inp, block)
+    check_close(out, ref * k, f"tile_m={tile_m} block={block}")
