@@ -44,6 +44,13 @@ enum {
     SGLK_W_INT8 = 2
 };
 
+/* output element types of the dense GEMM entry points */
+enum {
+    SGLK_OUT_BF16 = 0,
+    SGLK_OUT_F16 = 1,
+    SGLK_OUT_F32 = 2
+};
+
 int sglk_version(void);
 const char* sglk_last_error(void);
 /* number of compute units / name of device `dev` (host-side query used by the bench for roofline peaks) */
@@ -55,7 +62,8 @@ int sglk_device_cu_count(int dev);
  * Re-tiles `batch` row-major matrices [rows][cols] into the MFMA-operand tile order the GEMM kernels stream
  * (DESIGN.md §Packed weight layout).  Output has the same byte size, dtype and shape as the input, so it
  * stays an ordinary clonable tensor exactly like the reference's packed weights (bench_moe.py:53-58).
- * Requirements: rows % 16 == 0; cols % 64 == 0 (fp8/int8) or cols % 32 == 0 (bf16).
+ * Requirements: fp8/int8 rows % 16 == 0 and cols % 64 == 0; bf16 rows % 32 == 0 and cols % 8 == 0 (bf16 keeps the
+ * reference's VNNI-2 order, the one layout it pins with a live known-answer test, test_gemm.py:36-46).
  * --------------------------------------------------------------------------------------------------------- */
 int sglk_pack_weight(const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int wtype,
                      void* stream);
@@ -76,7 +84,8 @@ int sglk_unpack_weight(const void* src, void* dst, int64_t batch, int64_t rows, 
  * wtype   SGLK_W_FP8_E4M3: W8A16, w*_scale f32 [E][ceil(rows/block_n)][ceil(cols/block_k)], block_k == 128
  *         SGLK_W_BF16    : scales ignored
  *         SGLK_W_INT8    : W8A8 dynamic per-token activation quant, w1_scale [E][2N], w2_scale [E][K]
- * packed  != 0: weights are in sglk_pack_weight order (reference `is_vnni=True`); 0: plain row-major
+ * packed  bit 0: w1 is in sglk_pack_weight order, bit 1: w2 is (reference `is_vnni=True` = 3 when both shapes can be
+ *         packed); 0: plain row-major.  The tuned fp8 kernels need both bits; anything else runs the generic engine
  * topk_weights [M][topk] f32, topk_ids [M][topk] i32
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -101,6 +110,71 @@ typedef struct {
 
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
 int sglk_fused_experts(const sglk_fused_experts_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * shared_expert               replaces torch.ops.sgl_kernel.shared_expert_cpu
+ *     14-arg /root/reference/test_moe_fp8.py:87-88, test_moe_fp8_ext.py:60-61; 12-arg test_shared_experts.py:68,78
+ *   out = ( silu(x W1g^T) * (x W1u^T) ) W2^T + fused_out * routed_scaling_factor
+ * Same operand conventions as fused_experts with E = 1 (w1 [2N][K], w2 [K][N]); fused_out [M][K] bf16.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* hidden;
+    int64_t hidden_stride;
+    void* out;
+    int64_t out_stride;
+    const void* w1;
+    const void* w2;
+    const float* w1_scale;
+    const float* w2_scale;
+    const void* fused_out;
+    int64_t fused_out_stride;
+    float routed_scaling_factor;
+    int32_t M, N, K;
+    int32_t wtype;
+    int32_t packed;
+    int32_t block_n, block_k;
+    void* workspace;
+    size_t workspace_bytes;
+} sglk_shared_expert_args;
+
+size_t sglk_shared_expert_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype);
+int sglk_shared_expert(const sglk_shared_expert_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense weight GEMMs  out[M][N] = x[M][K] . w[N][K]^T (+ bias)
+ *   replaces weight_packed_linear (/root/reference/test_gemm.py:22-25)            wtype BF16, x bf16
+ *            fp8_scaled_mm_cpu    (/root/reference/test_gemm_fp8.py:54-62)        wtype FP8, block scales, x bf16
+ *            int8_scaled_mm_cpu   (/root/reference/test_gemm_int8.py:67)          wtype INT8, x int8 + x_scale[M]
+ *            int8_scaled_mm_with_quant (test_gemm_int8.py:72)                     wtype INT8, x bf16 (quantised here)
+ * x_is_int8 != 0: x is int8 [M][K] with per-row scales x_scale; else bf16.  w_scale: fp8 [ceil(N/bn)][K/128],
+ * int8 [N].  bias [N] f32 or NULL.  out_type SGLK_OUT_*.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* x;
+    int64_t x_stride;
+    int32_t x_is_int8;
+    const float* x_scale;
+    const void* w;
+    const float* w_scale;
+    const float* bias;
+    void* out;
+    int64_t out_stride;
+    int32_t out_type;
+    int32_t M, N, K;
+    int32_t wtype;
+    int32_t packed;
+    int32_t block_n, block_k;
+    void* workspace;
+    size_t workspace_bytes;
+} sglk_scaled_mm_args;
+
+size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
+int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
+
+/* per_token_quant_int8_cpu (/root/reference/test_gemm_int8.py:66): q = rint(x * 127/amax), scale = amax/127,
+ * amax = max(|row|, 1e-10).  x bf16 [rows][cols]. */
+int sglk_per_token_quant_int8(const void* x, int64_t x_stride, void* q, int64_t q_stride, float* scale,
+                              int64_t rows, int32_t cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Stages of fused_experts exposed for tests and profiling (same kernels the fused call launches).

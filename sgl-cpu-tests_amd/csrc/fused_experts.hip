@@ -17,10 +17,10 @@ struct StageTimer {
 };
 
 struct Workspace {
-    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, total;
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, xq, xs, ic1q, ic1s, total;
 };
 
-// tile height of the grouped GEMMs: 256-row tiles once experts see enough rows to fill them, else 128
+// tile height of the tuned grouped GEMMs: 256-row tiles once experts see enough rows to fill them, else 128
 int pick_tile_m(int M, int N, int K, int E, int topk) {
     const char* force = getenv("SGLK_MOE_TILE_M");
     const int64_t S = (int64_t)M * topk;
@@ -35,10 +35,10 @@ int pick_tile_m(int M, int N, int K, int E, int topk) {
     return (ok256 && S >= (int64_t)192 * E) ? 256 : kTileM;
 }
 
-Workspace plan_workspace(int M, int N, int K, int E, int topk) {
+Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     Workspace w{};
     const int64_t S = (int64_t)M * topk;
-    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kTileM);   // 128-row tiles bound the table size
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kGenericTileM);   // the smallest tile bounds the table size
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -50,19 +50,31 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk) {
     w.expert_off = take((size_t)(E + 1) * sizeof(int));
     w.tile_info = take((size_t)max_tiles * 4 * sizeof(int));
     w.num_tiles = take(sizeof(int));
-    w.ic1 = take((size_t)S * N * 2);
+    w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
+    if (wtype == SGLK_W_INT8) {   // W8A8: dynamically quantised activations of both GEMMs
+        w.xq = take((size_t)M * K);
+        w.xs = take((size_t)M * sizeof(float));
+        w.ic1q = take((size_t)S * N);
+        w.ic1s = take((size_t)S * sizeof(float));
+    }
     w.total = off;
     return w;
+}
+
+// shapes / layouts the tuned fp8 kernels (moe_gemm_fp8w*.hip) accept; everything else runs on the generic engine
+bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
+    return a->wtype == SGLK_W_FP8_E4M3 && (a->packed & 3) == 3 && a->N % 128 == 0 && a->K % 128 == 0 && a->block_k == 128 &&
+           a->block_n > 0 && a->block_n % 16 == 0 && (a->hidden_stride % 8) == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+           getenv("SGLK_FORCE_GENERIC") == nullptr;
 }
 
 }  // namespace
 
 extern "C" size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
                                                      int32_t wtype) {
-    (void)wtype;
     if (M < 0 || N <= 0 || K <= 0 || E <= 0 || topk <= 0) return 0;
-    return plan_workspace(M, N, K, E, topk).total;
+    return plan_workspace(M, N, K, E, topk, wtype).total;
 }
 
 extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream) {
@@ -75,23 +87,30 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
                  "fused_experts: null pointer");
     SGLK_REQUIRE(a->hidden_stride >= K && a->out_stride >= K, SGLK_ERR_INVALID, "fused_experts: row stride < K");
     SGLK_REQUIRE((int64_t)M * topk * (int64_t)(K > N ? K : N) < (1ll << 40), SGLK_ERR_SHAPE, "fused_experts: too large");
+    SGLK_REQUIRE(a->wtype == SGLK_W_BF16 || a->wtype == SGLK_W_FP8_E4M3 || a->wtype == SGLK_W_INT8, SGLK_ERR_INVALID,
+                 "fused_experts: unknown weight type %d", a->wtype);
     hipStream_t s = (hipStream_t)stream;
 
-    if (a->wtype != SGLK_W_FP8_E4M3)
-        SGLK_FAIL(SGLK_ERR_INVALID, "fused_experts: weight type %d not built yet (fp8 W8A16 only)", a->wtype);
-    SGLK_REQUIRE(a->packed, SGLK_ERR_INVALID,
-                 "fused_experts: fp8 weights must be packed with sglk_pack_weight (is_vnni=True)");
-    SGLK_REQUIRE(a->w1_scale && a->w2_scale, SGLK_ERR_INVALID, "fused_experts: fp8 needs w1_scale and w2_scale");
-    SGLK_REQUIRE(a->block_k == 128, SGLK_ERR_SHAPE, "fused_experts: block_size[1] must be 128 (got %d)", a->block_k);
-    SGLK_REQUIRE(a->block_n > 0 && a->block_n % 16 == 0, SGLK_ERR_SHAPE,
-                 "fused_experts: block_size[0] must be a positive multiple of 16 (got %d)", a->block_n);
-    SGLK_REQUIRE(N % 128 == 0 && K % 128 == 0, SGLK_ERR_SHAPE,
-                 "fused_experts(fp8): N (%d) and K (%d) must be multiples of 128", N, K);
-    SGLK_REQUIRE((a->hidden_stride % 8) == 0 && (a->out_stride % 8) == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
-                     ((uintptr_t)a->out % 16) == 0,
-                 SGLK_ERR_SHAPE, "fused_experts: hidden/out rows must be 16-byte aligned");
+    if (a->wtype == SGLK_W_FP8_E4M3) {
+        SGLK_REQUIRE(a->w1_scale && a->w2_scale, SGLK_ERR_INVALID, "fused_experts: fp8 needs w1_scale and w2_scale");
+        SGLK_REQUIRE(a->block_k == 128, SGLK_ERR_SHAPE, "fused_experts: block_size[1] must be 128 (got %d)", a->block_k);
+        SGLK_REQUIRE(a->block_n > 0 && a->block_n % 16 == 0, SGLK_ERR_SHAPE,
+                     "fused_experts: block_size[0] must be a positive multiple of 16 (got %d)", a->block_n);
+        SGLK_REQUIRE(N % 16 == 0, SGLK_ERR_SHAPE, "fused_experts(fp8): N (%d) must be a multiple of 16", N);
+    } else if (a->wtype == SGLK_W_INT8) {
+        SGLK_REQUIRE(a->w1_scale && a->w2_scale, SGLK_ERR_INVALID, "fused_experts: int8 needs w1_scale [E,2N] and w2_scale [E,K]");
+    }
+    if (a->packed & 1) {
+        const bool ok = a->wtype == SGLK_W_BF16 ? ((2 * N) % 32 == 0 && K % 8 == 0) : ((2 * N) % 16 == 0 && K % 64 == 0);
+        SGLK_REQUIRE(ok, SGLK_ERR_SHAPE, "fused_experts: w1 [%d][%d] cannot be in packed order; clear packed bit 0", 2 * N, K);
+    }
+    if (a->packed & 2) {
+        const bool ok = a->wtype == SGLK_W_BF16 ? (K % 32 == 0 && N % 8 == 0) : (K % 16 == 0 && N % 64 == 0);
+        SGLK_REQUIRE(ok, SGLK_ERR_SHAPE, "fused_experts: w2 [%d][%d] cannot be in packed order; clear packed bit 1", K, N);
+    }
+    SGLK_REQUIRE(((uintptr_t)a->out % 2) == 0 && ((uintptr_t)a->hidden % 2) == 0, SGLK_ERR_INVALID, "fused_experts: misaligned");
 
-    const Workspace w = plan_workspace(M, N, K, E, topk);
+    const Workspace w = plan_workspace(M, N, K, E, topk, a->wtype);
     SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "fused_experts: workspace %zu < required %zu",
                  a->workspace_bytes, w.total);
     SGLK_REQUIRE(((uintptr_t)a->workspace % 256) == 0, SGLK_ERR_INVALID, "fused_experts: workspace must be 256-B aligned");
@@ -111,63 +130,157 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     auto mark = [&](int i) {
         if (tm) hipEventRecord(tm->at(call, i), s);
     };
+    const bool tuned = tuned_fp8_ok(a);
+    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : kGenericTileM;
     mark(0);
-    const int tile_m = pick_tile_m(M, N, K, E, topk);
     int rc = sglk_moe_align(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                             ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
     if (rc != SGLK_OK) return rc;
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
-    MoeGemmParams g1{};
-    g1.x = (const uint16_t*)a->hidden;
-    g1.x_stride = a->hidden_stride;
-    g1.x_bytes = (int64_t)M * a->hidden_stride * 2;
-    g1.sorted_slot = sorted_slot;
-    g1.topk = topk;
-    g1.w = (const uint8_t*)a->w1;
-    g1.w_expert_stride = (int64_t)2 * N * K;
-    g1.w_scale = a->w1_scale;
-    g1.scale_rows = (int)ceil_div(2 * N, a->block_n);
-    g1.scale_cols = K / 128;
-    g1.block_n = a->block_n;
-    g1.C = K;
-    g1.n_half = N;
-    g1.tile_info = (const int4*)tile_info;
-    g1.num_tiles = num_tiles;
-    g1.n_tiles = tile_m == 256 ? N / 128 : N / 64;
-    g1.out = ic1;
-    g1.out_stride = N;
-    g1.topk_weights = nullptr;
-    rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s)
-                       : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
-    if (rc != SGLK_OK) return rc;
-    mark(2);
+    if (tuned) {
+        MoeGemmParams g1{};
+        g1.x = (const uint16_t*)a->hidden;
+        g1.x_stride = a->hidden_stride;
+        g1.x_bytes = (int64_t)M * a->hidden_stride * 2;
+        g1.sorted_slot = sorted_slot;
+        g1.topk = topk;
+        g1.w = (const uint8_t*)a->w1;
+        g1.w_expert_stride = (int64_t)2 * N * K;
+        g1.w_scale = a->w1_scale;
+        g1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+        g1.scale_cols = K / 128;
+        g1.block_n = a->block_n;
+        g1.C = K;
+        g1.n_half = N;
+        g1.tile_info = (const int4*)tile_info;
+        g1.num_tiles = num_tiles;
+        g1.n_tiles = tile_m == 256 ? N / 128 : N / 64;
+        g1.out = ic1;
+        g1.out_stride = N;
+        g1.topk_weights = nullptr;
+        rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s)
+                           : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
 
-    MoeGemmParams g2{};
-    g2.x = ic1;
-    g2.x_stride = N;
-    g2.x_bytes = (int64_t)M * topk * N * 2;
-    g2.sorted_slot = sorted_slot;
-    g2.topk = topk;
-    g2.w = (const uint8_t*)a->w2;
-    g2.w_expert_stride = (int64_t)K * N;
-    g2.w_scale = a->w2_scale;
-    g2.scale_rows = (int)ceil_div(K, a->block_n);
-    g2.scale_cols = N / 128;
-    g2.block_n = a->block_n;
-    g2.C = N;
-    g2.n_half = 0;
-    g2.tile_info = (const int4*)tile_info;
-    g2.num_tiles = num_tiles;
-    g2.n_tiles = tile_m == 256 ? K / 256 : K / 128;
-    g2.out = ic2;
-    g2.out_stride = K;
-    g2.topk_weights = a->topk_weights;
-    rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s)
-                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
-    if (rc != SGLK_OK) return rc;
-    mark(3);
+        MoeGemmParams g2{};
+        g2.x = ic1;
+        g2.x_stride = N;
+        g2.x_bytes = (int64_t)M * topk * N * 2;
+        g2.sorted_slot = sorted_slot;
+        g2.topk = topk;
+        g2.w = (const uint8_t*)a->w2;
+        g2.w_expert_stride = (int64_t)K * N;
+        g2.w_scale = a->w2_scale;
+        g2.scale_rows = (int)ceil_div(K, a->block_n);
+        g2.scale_cols = N / 128;
+        g2.block_n = a->block_n;
+        g2.C = N;
+        g2.n_half = 0;
+        g2.tile_info = (const int4*)tile_info;
+        g2.num_tiles = num_tiles;
+        g2.n_tiles = tile_m == 256 ? K / 256 : K / 128;
+        g2.out = ic2;
+        g2.out_stride = K;
+        g2.topk_weights = a->topk_weights;
+        rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s)
+                           : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else {
+        // generic engine: any shape / weight type / row-major weights (gemm_generic.hip)
+        const int wes = a->wtype == SGLK_W_BF16 ? 2 : 1;
+        GenericGemmParams g1{};
+        g1.x = a->hidden;
+        g1.x_type = SGLK_W_BF16;
+        g1.x_stride = a->hidden_stride;
+        if (a->wtype == SGLK_W_INT8) {
+            int8_t* xq = (int8_t*)(ws + w.xq);
+            float* xs = (float*)(ws + w.xs);
+            rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+            if (rc != SGLK_OK) return rc;
+            g1.x = xq;
+            g1.x_type = SGLK_W_INT8;
+            g1.x_stride = K;
+            g1.x_row_scale = xs;
+        }
+        g1.sorted_slot = sorted_slot;
+        g1.topk = topk;
+        g1.gather = GG_GATHER_TOKEN;
+        g1.tile_info = (const int4*)tile_info;
+        g1.num_tiles = num_tiles;
+        g1.n_tiles = (int)ceil_div(N, 32);
+        g1.w = a->w1;
+        g1.w_type = a->wtype;
+        g1.packed = a->packed & 1;
+        g1.w_expert_stride = (int64_t)2 * N * K * wes;
+        g1.C = K;
+        g1.w_scale = a->w1_scale;
+        if (a->wtype == SGLK_W_FP8_E4M3) {
+            g1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+            g1.scale_cols = (int)ceil_div(K, 128);
+            g1.block_n = a->block_n;
+        } else {
+            g1.scale_rows = 2 * N;   // int8: one scale per weight row
+            g1.scale_cols = 1;
+            g1.block_n = 1;
+        }
+        g1.n_half = N;
+        g1.n_out = N;
+        g1.out = ic1;
+        g1.out_type = a->wtype == SGLK_W_INT8 ? SGLK_OUT_F32 : SGLK_OUT_BF16;
+        g1.out_stride = N;
+        rc = launch_gemm_generic(GG_GATE_UP, g1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+
+        GenericGemmParams g2{};
+        g2.x = ic1;
+        g2.x_type = SGLK_W_BF16;
+        g2.x_stride = N;
+        if (a->wtype == SGLK_W_INT8) {
+            int8_t* q = (int8_t*)(ws + w.ic1q);
+            float* qs = (float*)(ws + w.ic1s);
+            // rows of ic1 are positions; only the first (#valid slots) are defined, the rest is never read back
+            rc = launch_quant_int8_rows_f32((const float*)ic1, N, q, N, qs, (int64_t)M * topk, N, 1e-7f, s);
+            if (rc != SGLK_OK) return rc;
+            g2.x = q;
+            g2.x_type = SGLK_W_INT8;
+            g2.x_row_scale = qs;
+        }
+        g2.sorted_slot = sorted_slot;
+        g2.topk = topk;
+        g2.gather = GG_GATHER_NONE;
+        g2.tile_info = (const int4*)tile_info;
+        g2.num_tiles = num_tiles;
+        g2.n_tiles = (int)ceil_div(K, 64);
+        g2.w = a->w2;
+        g2.w_type = a->wtype;
+        g2.packed = (a->packed >> 1) & 1;
+        g2.w_expert_stride = (int64_t)K * N * wes;
+        g2.C = N;
+        g2.w_scale = a->w2_scale;
+        if (a->wtype == SGLK_W_FP8_E4M3) {
+            g2.scale_rows = (int)ceil_div(K, a->block_n);
+            g2.scale_cols = (int)ceil_div(N, 128);
+            g2.block_n = a->block_n;
+        } else {
+            g2.scale_rows = K;
+            g2.scale_cols = 1;
+            g2.block_n = 1;
+        }
+        g2.n_out = K;
+        g2.out = ic2;
+        g2.out_type = SGLK_OUT_BF16;
+        g2.out_stride = K;
+        g2.scatter = 1;
+        g2.topk_weights = a->topk_weights;
+        rc = launch_gemm_generic(GG_DOWN, g2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    }
 
     rc = launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
     mark(4);

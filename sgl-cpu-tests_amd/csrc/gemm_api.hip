@@ -1,0 +1,219 @@
+// Dense entry points of the C-ABI built on the generic engine: shared_expert, scaled_mm (fp8 / int8 / bf16 weights).
+#include "moe_internal.h"
+
+using namespace sglk;
+
+namespace {
+
+struct DenseWs {
+    size_t tile_info, num_tiles, ic1, xq, xs, ic1q, ic1s, total;
+};
+
+DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
+    DenseWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes ? bytes : 1, 256);
+        return o;
+    };
+    const int tiles = (int)ceil_div(M > 0 ? M : 1, kGenericTileM);
+    w.tile_info = take((size_t)tiles * 16);
+    w.num_tiles = take(4);
+    if (need_ic1) w.ic1 = take((size_t)M * N * (int8_act ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until quantised
+    if (int8_act) {
+        w.xq = take((size_t)M * K);
+        w.xs = take((size_t)M * 4);
+        if (need_ic1) {
+            w.ic1q = take((size_t)M * N);
+            w.ic1s = take((size_t)M * 4);
+        }
+    }
+    w.total = off;
+    return w;
+}
+
+void fill_weight(GenericGemmParams& g, const void* w, const float* scale, int wtype, int packed, int rows, int C,
+                 int block_n) {
+    g.w = w;
+    g.w_type = wtype;
+    g.packed = packed;
+    g.w_expert_stride = 0;
+    g.C = C;
+    g.w_scale = scale;
+    if (wtype == SGLK_W_FP8_E4M3) {
+        g.scale_rows = (int)ceil_div(rows, block_n);
+        g.scale_cols = (int)ceil_div(C, 128);
+        g.block_n = block_n;
+    } else {
+        g.scale_rows = rows;
+        g.scale_cols = 1;
+        g.block_n = 1;
+    }
+}
+
+int check_weight(const char* op, int wtype, int packed, int rows, int C, const float* scale, int block_n, int block_k) {
+    SGLK_REQUIRE(wtype == SGLK_W_BF16 || wtype == SGLK_W_FP8_E4M3 || wtype == SGLK_W_INT8, SGLK_ERR_INVALID,
+                 "%s: unknown weight type %d", op, wtype);
+    if (wtype == SGLK_W_FP8_E4M3) {
+        SGLK_REQUIRE(scale, SGLK_ERR_INVALID, "%s: fp8 weights need block scales", op);
+        SGLK_REQUIRE(block_k == 128, SGLK_ERR_SHAPE, "%s: block_size[1] must be 128 (got %d)", op, block_k);
+        SGLK_REQUIRE(block_n > 0 && block_n % 16 == 0, SGLK_ERR_SHAPE, "%s: block_size[0] must be a multiple of 16 (got %d)", op, block_n);
+    } else if (wtype == SGLK_W_INT8) {
+        SGLK_REQUIRE(scale, SGLK_ERR_INVALID, "%s: int8 weights need per-channel scales", op);
+    }
+    if (packed) {
+        const bool ok = wtype == SGLK_W_BF16 ? (rows % 32 == 0 && C % 8 == 0) : (rows % 16 == 0 && C % 64 == 0);
+        SGLK_REQUIRE(ok, SGLK_ERR_SHAPE, "%s: a [%d][%d] weight cannot be in packed order; pass packed=0", op, rows, C);
+    }
+    return SGLK_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sglk_shared_expert_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype) {
+    if (M < 0 || N <= 0 || K <= 0) return 0;
+    return plan_dense(M, N, K, true, wtype == SGLK_W_INT8).total;
+}
+
+extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "shared_expert: null args");
+    const int M = a->M, N = a->N, K = a->K;
+    SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, SGLK_ERR_INVALID, "shared_expert: bad sizes M=%d N=%d K=%d", M, N, K);
+    SGLK_REQUIRE(a->w1 && a->w2 && a->workspace, SGLK_ERR_INVALID, "shared_expert: null pointer");
+    SGLK_REQUIRE(M == 0 || (a->hidden && a->out && a->fused_out), SGLK_ERR_INVALID, "shared_expert: null pointer");
+    SGLK_REQUIRE(a->hidden_stride >= K && a->out_stride >= K && a->fused_out_stride >= K, SGLK_ERR_INVALID,
+                 "shared_expert: row stride < K");
+    int rc = check_weight("shared_expert", a->wtype, a->packed & 1, 2 * N, K, a->w1_scale, a->block_n, a->block_k);
+    if (rc != SGLK_OK) return rc;
+    rc = check_weight("shared_expert", a->wtype, (a->packed >> 1) & 1, K, N, a->w2_scale, a->block_n, a->block_k);
+    if (rc != SGLK_OK) return rc;
+    if (a->wtype == SGLK_W_FP8_E4M3) SGLK_REQUIRE(N % 16 == 0, SGLK_ERR_SHAPE, "shared_expert(fp8): N (%d) must be a multiple of 16", N);
+    const bool i8 = a->wtype == SGLK_W_INT8;
+    const DenseWs w = plan_dense(M, N, K, true, i8);
+    SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "shared_expert: workspace %zu < required %zu",
+                 a->workspace_bytes, w.total);
+    if (M == 0) return SGLK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)a->workspace;
+    int4* tile_info = (int4*)(ws + w.tile_info);
+    int* num_tiles = (int*)(ws + w.num_tiles);
+    uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
+    const int tiles = (int)ceil_div(M, kGenericTileM);
+    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, s);
+    if (rc != SGLK_OK) return rc;
+
+    GenericGemmParams g1{};
+    g1.x = a->hidden;
+    g1.x_type = SGLK_W_BF16;
+    g1.x_stride = a->hidden_stride;
+    if (i8) {
+        rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, (int8_t*)(ws + w.xq), K,
+                                    (float*)(ws + w.xs), M, K, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        g1.x = ws + w.xq;
+        g1.x_type = SGLK_W_INT8;
+        g1.x_stride = K;
+        g1.x_row_scale = (const float*)(ws + w.xs);
+    }
+    g1.topk = 1;
+    g1.gather = GG_GATHER_NONE;
+    g1.tile_info = tile_info;
+    g1.num_tiles = num_tiles;
+    g1.n_tiles = (int)ceil_div(N, 32);
+    fill_weight(g1, a->w1, a->w1_scale, a->wtype, a->packed & 1, 2 * N, K, a->block_n);
+    g1.n_half = N;
+    g1.n_out = N;
+    g1.out = ic1;
+    g1.out_type = i8 ? SGLK_OUT_F32 : SGLK_OUT_BF16;
+    g1.out_stride = N;
+    rc = launch_gemm_generic(GG_GATE_UP, g1, tiles, s);
+    if (rc != SGLK_OK) return rc;
+
+    GenericGemmParams g2{};
+    g2.x = ic1;
+    g2.x_type = SGLK_W_BF16;
+    g2.x_stride = N;
+    if (i8) {
+        rc = launch_quant_int8_rows_f32((const float*)ic1, N, (int8_t*)(ws + w.ic1q), N, (float*)(ws + w.ic1s), M, N,
+                                        1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        g2.x = ws + w.ic1q;
+        g2.x_type = SGLK_W_INT8;
+        g2.x_row_scale = (const float*)(ws + w.ic1s);
+    }
+    g2.topk = 1;
+    g2.gather = GG_GATHER_NONE;
+    g2.tile_info = tile_info;
+    g2.num_tiles = num_tiles;
+    g2.n_tiles = (int)ceil_div(K, 64);
+    fill_weight(g2, a->w2, a->w2_scale, a->wtype, (a->packed >> 1) & 1, K, N, a->block_n);
+    g2.n_out = K;
+    g2.out = a->out;
+    g2.out_type = SGLK_OUT_BF16;
+    g2.out_stride = a->out_stride;
+    g2.addend = a->fused_out;
+    g2.addend_stride = a->fused_out_stride;
+    g2.addend_scale = a->routed_scaling_factor;
+    return launch_gemm_generic(GG_PLAIN, g2, tiles, s);
+}
+
+extern "C" size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8) {
+    if (M < 0 || N <= 0 || K <= 0) return 0;
+    return plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8).total;
+}
+
+extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "scaled_mm: null args");
+    const int M = a->M, N = a->N, K = a->K;
+    SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, SGLK_ERR_INVALID, "scaled_mm: bad sizes M=%d N=%d K=%d", M, N, K);
+    SGLK_REQUIRE(a->w && a->workspace, SGLK_ERR_INVALID, "scaled_mm: null pointer");
+    SGLK_REQUIRE(M == 0 || (a->x && a->out), SGLK_ERR_INVALID, "scaled_mm: null pointer");
+    SGLK_REQUIRE(a->x_stride >= K && a->out_stride >= N, SGLK_ERR_INVALID, "scaled_mm: row stride too small");
+    SGLK_REQUIRE(a->out_type >= SGLK_OUT_BF16 && a->out_type <= SGLK_OUT_F32, SGLK_ERR_INVALID, "scaled_mm: bad out_type");
+    int rc = check_weight("scaled_mm", a->wtype, a->packed, N, K, a->w_scale, a->block_n, a->block_k);
+    if (rc != SGLK_OK) return rc;
+    if (a->x_is_int8) {
+        SGLK_REQUIRE(a->wtype == SGLK_W_INT8 && a->x_scale, SGLK_ERR_INVALID,
+                     "scaled_mm: int8 activations need int8 weights and x_scale");
+    }
+    const bool quant_here = a->wtype == SGLK_W_INT8 && !a->x_is_int8;
+    const DenseWs w = plan_dense(M, N, K, false, quant_here);
+    SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "scaled_mm: workspace %zu < required %zu",
+                 a->workspace_bytes, w.total);
+    if (M == 0) return SGLK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)a->workspace;
+    int4* tile_info = (int4*)(ws + w.tile_info);
+    int* num_tiles = (int*)(ws + w.num_tiles);
+    const int tiles = (int)ceil_div(M, kGenericTileM);
+    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, s);
+    if (rc != SGLK_OK) return rc;
+
+    GenericGemmParams g{};
+    g.x = a->x;
+    g.x_type = a->x_is_int8 ? SGLK_W_INT8 : SGLK_W_BF16;
+    g.x_stride = a->x_stride;
+    g.x_row_scale = a->x_scale;
+    if (quant_here) {
+        rc = launch_quant_int8_rows((const uint16_t*)a->x, a->x_stride, (int8_t*)(ws + w.xq), K, (float*)(ws + w.xs),
+                                    M, K, 1e-10f, s);
+        if (rc != SGLK_OK) return rc;
+        g.x = ws + w.xq;
+        g.x_type = SGLK_W_INT8;
+        g.x_stride = K;
+        g.x_row_scale = (const float*)(ws + w.xs);
+    }
+    g.topk = 1;
+    g.gather = GG_GATHER_NONE;
+    g.tile_info = tile_info;
+    g.num_tiles = num_tiles;
+    g.n_tiles = (int)ceil_div(N, 64);
+    fill_weight(g, a->w, a->w_scale, a->wtype, a->packed, N, K, a->block_n);
+    g.n_out = N;
+    g.out = a->out;
+    g.out_type = a->out_type;
+    g.out_stride = a->out_stride;
+    g.bias = a->bias;
+    return launch_gemm_generic(GG_PLAIN, g, tiles, s);
+}

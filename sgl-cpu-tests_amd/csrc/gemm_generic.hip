@@ -1,0 +1,303 @@
+// Generic grouped / dense GEMM engine: any shape, any of the reference's weight types, packed or row-major weights.
+//
+// This is the kernel behind every GEMM-shaped operator that is NOT the tuned fp8 hot path:
+//   fused_experts_cpu  bf16 / int8-w8a8 / fp8 with shapes the tuned tiles cannot take, is_vnni=False
+//                      (/root/reference/test_moe.py:79-92, test_moe_int8.py:129, test_moe_offloading_cpu.py:123-137)
+//   shared_expert_cpu  (/root/reference/test_moe_fp8.py:87-88, test_shared_experts.py:68,78)
+//   fp8_scaled_mm_cpu, int8_scaled_mm_cpu, weight_packed_linear
+//                      (/root/reference/test_gemm_fp8.py:54-62, test_gemm_int8.py:67, test_gemm.py:22-25)
+//
+// Both operands are converted EXACTLY to bf16 while they are staged into LDS (fp8 e4m3 and int8 values are exactly
+// representable in bf16) and multiplied on mfma_f32_16x16x32_bf16 with fp32 accumulation, so every scale is applied
+// in fp32 to fp32 sums: fp8 block scales to the per-K-block partial sum (acc += s * partial), int8 per-token x
+// per-channel scales in the epilogue.  That is the arithmetic of the reference's oracles
+// (/root/reference/test_gemm_int8.py:25-47: float matmul of the int8 values, then As * C * Bs).
+//
+// Tile: 64 tokens x 64 weight rows x 64 k, 256 threads; weights are the MFMA A operand (see moe_gemm_fp8w.hip).
+// Register-staged (global -> VGPR -> convert -> LDS), single LDS buffer: built for coverage, not for the roofline —
+// every access is bounds-guarded (rows, columns and the K tail are zero-filled).
+#include "sglk_common.h"
+#include "moe_internal.h"
+
+namespace sglk {
+
+namespace gg {
+
+constexpr int kBM = kGenericTileM;   // 64 tokens
+constexpr int kBN = 64;              // weight rows per tile
+constexpr int kBK = 64;
+
+// 8 consecutive reduction elements of one row -> 8 bf16 (16 bytes), exact.  `k` is a multiple of 8.
+template <int TYPE>
+SGLK_DEV uint4 load8_as_bf16(const unsigned char* row_base, int k, int C) {
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (k >= C) return out;
+    if (TYPE == SGLK_W_BF16) {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(row_base) + k;
+        if (k + 8 <= C && (reinterpret_cast<uintptr_t>(p) & 15) == 0) return *reinterpret_cast<const uint4*>(p);
+        unsigned short v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (k + j < C) ? p[j] : (unsigned short)0;
+        out.x = v[0] | ((unsigned)v[1] << 16); out.y = v[2] | ((unsigned)v[3] << 16);
+        out.z = v[4] | ((unsigned)v[5] << 16); out.w = v[6] | ((unsigned)v[7] << 16);
+        return out;
+    }
+    const unsigned char* p = row_base + k;
+    unsigned char b[8];
+    if (k + 8 <= C && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b[j] = (raw.x >> (8 * j)) & 0xff; b[4 + j] = (raw.y >> (8 * j)) & 0xff; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (k + j < C) ? p[j] : (unsigned char)0;
+    }
+    float f[8];
+    if (TYPE == SGLK_W_FP8_E4M3) {
+        const unsigned lo = b[0] | (b[1] << 8) | (b[2] << 16) | ((unsigned)b[3] << 24);
+        const unsigned hi = b[4] | (b[5] << 8) | (b[6] << 16) | ((unsigned)b[7] << 24);
+        const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+        const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+        f[0] = a0[0]; f[1] = a0[1]; f[2] = a1[0]; f[3] = a1[1]; f[4] = a2[0]; f[5] = a2[1]; f[6] = a3[0]; f[7] = a3[1];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)(signed char)b[j];
+    }
+    out.x = pack_bf16x2(f[0], f[1]); out.y = pack_bf16x2(f[2], f[3]);
+    out.z = pack_bf16x2(f[4], f[5]); out.w = pack_bf16x2(f[6], f[7]);
+    return out;
+}
+
+// the k-octet (row, k..k+7) of ONE packed matrix [R][C] (pack.hip orders) as 8 bf16; k % 8 == 0, k < C
+template <int TYPE>
+SGLK_DEV uint4 load_packed_octet(const unsigned char* mat, int row, int k, int C) {
+    if (TYPE == SGLK_W_BF16) {
+        // reference VNNI-2 order [R/32][C/2][32][2]: the octet is four (k, k+1) pairs, 32 pairs apart
+        const unsigned* pairs = reinterpret_cast<const unsigned*>(mat) + ((int64_t)(row >> 5) * (C >> 1) + (k >> 1)) * 32 + (row & 31);
+        return make_uint4(pairs[0], pairs[32], pairs[64], pairs[96]);
+    }
+    const int64_t tile = (int64_t)(row >> 4) * (C >> 6) + (k >> 6);
+    const int kk = k & 63;
+    int64_t off;
+    if (TYPE == SGLK_W_FP8_E4M3) off = tile * 1024 + ((((kk & 31) >> 3) * 16 + (row & 15)) * 16) + (kk >> 5) * 8;
+    else off = tile * 1024 + (((kk >> 4) * 16 + (row & 15)) * 16) + (kk & 8);
+    return load8_as_bf16<TYPE>(mat + off, 0, 8);
+}
+
+template <int WTYPE, int XTYPE, int MODE>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kBM * 128];
+    unsigned char* sx = smem;
+    unsigned char* sw = smem + kBM * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int live = p.num_tiles[0] * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int mtile = blockIdx.x / p.n_tiles;
+    const int ntile = blockIdx.x - mtile * p.n_tiles;
+    const int4 ti = p.tile_info[mtile];
+    const int e = ti.x, pos0 = ti.y, rows = ti.z;
+
+    const int C = p.C;
+    constexpr int kOutCols = (MODE == GG_GATE_UP) ? kBN / 2 : kBN;    // output columns per tile
+    const int col0 = ntile * kOutCols;
+
+    // weight row of tile row i (0..63); -1 = out of range (zero-filled)
+    auto weight_row = [&](int i) -> int {
+        if (MODE == GG_GATE_UP) {
+            const int c = col0 + (i & 31);
+            if (c >= p.n_out) return -1;
+            return (i < 32) ? c : p.n_half + c;
+        }
+        const int c = col0 + i;
+        return c < p.n_out ? c : -1;
+    };
+
+    // ---- staging assignments: 512 octet-chunks per operand tile, 2 per thread -------------------------------------
+    int x_row[2], x_ch[2], w_row[2];
+    const unsigned char* x_base[2];
+    const unsigned char* w_base[2];
+    const unsigned char* wexp = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)e * p.w_expert_stride;
+    constexpr int WES = (WTYPE == SGLK_W_BF16) ? 2 : 1;
+    constexpr int XES = (XTYPE == SGLK_W_BF16) ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        x_row[i] = c >> 3;
+        x_ch[i] = c & 7;
+        const int r = x_row[i];
+        x_base[i] = nullptr;
+        if (r < rows) {
+            int64_t xr;
+            if (p.gather == GG_GATHER_TOKEN) xr = p.sorted_slot[pos0 + r] / p.topk;
+            else xr = pos0 + r;
+            x_base[i] = reinterpret_cast<const unsigned char*>(p.x) + xr * p.x_stride * XES;
+        }
+        w_row[i] = weight_row(r);
+        w_base[i] = (w_row[i] >= 0 && !p.packed) ? wexp + (int64_t)w_row[i] * C * WES : nullptr;
+    }
+
+    // ---- fragment read offsets --------------------------------------------------------------------------------------
+    // wave w: token tile w (16 tokens), all four 16-row weight tiles
+    const int fr = lane & 15, fg = lane >> 4;
+    int xoff[2], woff[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int xr = wave * 16 + fr;
+        xoff[ks] = xr * 128 + (((ks * 4 + fg) ^ (xr & 7)) << 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int wr = nt * 16 + fr;
+            woff[nt][ks] = wr * 128 + (((ks * 4 + fg) ^ (wr & 7)) << 4);
+        }
+    }
+
+    f32x4 acc[4], tacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tacc[nt] = acc[nt]; }
+
+    // fp8 block scale of the wave's weight tile nt for K block kb (tile rows share a block: block_n % 16 == 0)
+    const float* scale_e = (WTYPE == SGLK_W_FP8_E4M3) ? p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols : nullptr;
+    int srow[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int wr = weight_row(nt * 16);
+        srow[nt] = (WTYPE == SGLK_W_FP8_E4M3 && wr >= 0) ? wr / p.block_n : 0;
+    }
+
+    const int stages = (C + kBK - 1) / kBK;
+    for (int kt = 0; kt < stages; ++kt) {
+        uint4 xv[2], wv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = kt * kBK + x_ch[i] * 8;
+            xv[i] = x_base[i] ? load8_as_bf16<XTYPE>(x_base[i], k, C) : make_uint4(0, 0, 0, 0);
+            if (w_row[i] < 0) {
+                wv[i] = make_uint4(0, 0, 0, 0);
+            } else if (p.packed) {
+                // packed shapes have C % 64 == 0 (fp8/int8) or C % 8 == 0 (bf16): octets are complete
+                wv[i] = (k < C) ? load_packed_octet<WTYPE>(wexp, w_row[i], k, C) : make_uint4(0, 0, 0, 0);
+            } else {
+                wv[i] = load8_as_bf16<WTYPE>(w_base[i], k, C);
+            }
+        }
+        __syncthreads();   // previous stage's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int off = x_row[i] * 128 + ((x_ch[i] ^ (x_row[i] & 7)) << 4);
+            *reinterpret_cast<uint4*>(sx + off) = xv[i];
+            *reinterpret_cast<uint4*>(sw + off) = wv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sx + xoff[ks]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(sw + woff[nt][ks]);
+                if (WTYPE == SGLK_W_FP8_E4M3) tacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, tacc[nt], 0, 0, 0);
+                else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[nt], 0, 0, 0);
+            }
+        }
+        if (WTYPE == SGLK_W_FP8_E4M3 && ((kt & 1) == 1 || kt == stages - 1)) {
+            const int kb = kt >> 1;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt] += scale_e[srow[nt] * p.scale_cols + kb] * tacc[nt];
+                tacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    const int r = wave * 16 + fr;          // token row of this lane inside the tile
+    if (r >= rows) return;
+    const int q4 = fg * 4;                 // the lane's 4 registers = weight rows q4..q4+3 of each 16-row tile
+    int64_t xrow_idx;                       // row index into x (for the int8 activation scale)
+    int slot = 0;
+    if (p.gather == GG_GATHER_TOKEN || p.scatter) slot = p.sorted_slot[pos0 + r];
+    xrow_idx = (p.gather == GG_GATHER_TOKEN) ? slot / p.topk : pos0 + r;
+    const float xs = (XTYPE == SGLK_W_INT8) ? p.x_row_scale[xrow_idx] : 1.f;
+    const int64_t orow = p.scatter ? slot : (int64_t)(pos0 + r);
+    const float* wcs = (WTYPE == SGLK_W_INT8) ? p.w_scale + (int64_t)e * p.scale_rows : nullptr;   // per weight row
+
+    auto store = [&](int col, float v) {
+        if (p.out_type == SGLK_OUT_F32) reinterpret_cast<float*>(p.out)[orow * p.out_stride + col] = v;
+        else if (p.out_type == SGLK_OUT_F16) reinterpret_cast<_Float16*>(p.out)[orow * p.out_stride + col] = (_Float16)v;
+        else reinterpret_cast<unsigned short*>(p.out)[orow * p.out_stride + col] = f32_to_bf16_bits(v);
+    };
+
+    if (MODE == GG_GATE_UP) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = col0 + nt * 16 + q4 + j;
+                if (c >= p.n_out) continue;
+                float g = acc[nt][j], u = acc[nt + 2][j];
+                if (WTYPE == SGLK_W_INT8) { g *= xs * wcs[c]; u *= xs * wcs[p.n_half + c]; }
+                store(c, silu_f32(g) * u);
+            }
+    } else {
+        const float tw = (MODE == GG_DOWN) ? p.topk_weights[slot] : 1.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = col0 + nt * 16 + q4 + j;
+                if (c >= p.n_out) continue;
+                float v = acc[nt][j];
+                if (WTYPE == SGLK_W_INT8) v *= xs * wcs[c];
+                if (p.bias) v += p.bias[c];
+                if (p.addend) v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.addend)[orow * p.addend_stride + c]) * p.addend_scale;
+                store(c, v * tw);
+            }
+    }
+}
+
+}  // namespace gg
+
+// m-tile table of a dense [M] x ... problem: one "expert", rows in natural order
+__global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_tiles) {
+    const int n = (M + tile_m - 1) / tile_m;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int rows = M - i * tile_m < tile_m ? M - i * tile_m : tile_m;
+        tile_info[i] = make_int4(0, i * tile_m, rows, 0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) num_tiles[0] = n;
+}
+
+int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, hipStream_t stream) {
+    const int n = (M + tile_m - 1) / tile_m;
+    int blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dense_tiles_kernel, dim3(blocks), dim3(256), 0, stream, M, tile_m, tile_info, num_tiles);
+    SGLK_CHECK_LAUNCH("dense_tiles");
+    return SGLK_OK;
+}
+
+int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream) {
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks == 0) return SGLK_OK;
+    const dim3 grid((unsigned)blocks), block(256);
+#define GG_LAUNCH(WT, XT, MD) hipLaunchKernelGGL((gg::gemm_generic_kernel<WT, XT, MD>), grid, block, 0, stream, p)
+#define GG_MODES(WT, XT)                                  \
+    do {                                                  \
+        if (mode == GG_GATE_UP) GG_LAUNCH(WT, XT, GG_GATE_UP); \
+        else if (mode == GG_DOWN) GG_LAUNCH(WT, XT, GG_DOWN);  \
+        else GG_LAUNCH(WT, XT, GG_PLAIN);                 \
+    } while (0)
+    if (p.w_type == SGLK_W_BF16 && p.x_type == SGLK_W_BF16) GG_MODES(SGLK_W_BF16, SGLK_W_BF16);
+    else if (p.w_type == SGLK_W_FP8_E4M3 && p.x_type == SGLK_W_BF16) GG_MODES(SGLK_W_FP8_E4M3, SGLK_W_BF16);
+    else if (p.w_type == SGLK_W_INT8 && p.x_type == SGLK_W_INT8) GG_MODES(SGLK_W_INT8, SGLK_W_INT8);
+    else SGLK_FAIL(SGLK_ERR_INVALID, "gemm_generic: unsupported operand types w=%d x=%d", p.w_type, p.x_type);
+#undef GG_MODES
+#undef GG_LAUNCH
+    SGLK_CHECK_LAUNCH("gemm_generic");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

@@ -36,9 +36,35 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
     }
 }
 
+// any K / alignment: one element per thread (only the odd shapes of the generic path come here)
+__global__ __launch_bounds__(256) void moe_combine_scalar_kernel(const uint16_t* __restrict__ ic2,
+                                                                 const int32_t* __restrict__ topk_ids,
+                                                                 uint16_t* __restrict__ out, int64_t out_stride, int M,
+                                                                 int K, int E, int topk) {
+    const int64_t total = (int64_t)M * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / K), c = (int)(i - (int64_t)m * K);
+        float sum = 0.f;
+        for (int j = 0; j < topk; ++j) {
+            const int e = topk_ids[(int64_t)m * topk + j];
+            if (e < 0 || e >= E) continue;
+            sum += bf16_bits_to_f32(ic2[((int64_t)m * topk + j) * K + c]);
+        }
+        out[(int64_t)m * out_stride + c] = f32_to_bf16_bits(sum);
+    }
+}
+
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
                        int K, int E, int topk, hipStream_t stream) {
     if (M == 0) return SGLK_OK;
+    if (K % 8 != 0 || out_stride % 8 != 0 || ((uintptr_t)out % 16) != 0) {
+        int64_t nb = ceil_div((int64_t)M * K, 256);
+        if (nb > 256 * 8) nb = 256 * 8;
+        hipLaunchKernelGGL(moe_combine_scalar_kernel, dim3((unsigned)nb), dim3(256), 0, stream, ic2, topk_ids, out,
+                           out_stride, M, K, E, topk);
+        SGLK_CHECK_LAUNCH("moe_combine");
+        return SGLK_OK;
+    }
     const int64_t total = (int64_t)M * (K >> 3);
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 8) blocks = 256 * 8;

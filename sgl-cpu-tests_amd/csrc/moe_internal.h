@@ -33,6 +33,51 @@ int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipSt
 // 256-token x 256-row tiles, 8 waves, 3-deep LDS-DMA ring (moe_gemm_fp8w_256.hip); tile table built with tile_m = 256
 int launch_moe_gemm_fp8w_256(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
+// ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
+constexpr int kGenericTileM = 64;
+enum { GG_GATE_UP = 0, GG_DOWN = 1, GG_PLAIN = 2 };
+enum { GG_GATHER_NONE = 0, GG_GATHER_TOKEN = 1 };   // x row = position | sorted_slot[position] / topk
+
+struct GenericGemmParams {
+    const void* x;                // tokens: bf16 or int8 (x_type = SGLK_W_BF16 / SGLK_W_INT8)
+    int x_type;
+    int64_t x_stride;             // elements
+    const float* x_row_scale;     // int8 activations: per x row
+    const int* sorted_slot;
+    int topk;
+    int gather;
+    const int4* tile_info;        // 64-row m-tiles
+    const int* num_tiles;
+    int n_tiles;                  // tiles along output columns
+    const void* w;                // [E][R][C]
+    int w_type;
+    int packed;
+    int64_t w_expert_stride;      // bytes
+    int C;                        // reduction length
+    const float* w_scale;         // fp8: [E][scale_rows][scale_cols] block scales; int8: [E][scale_rows] per weight row
+    int scale_rows, scale_cols, block_n;
+    int n_half;                   // GATE_UP: row offset of the "up" half
+    int n_out;                    // output columns
+    void* out;
+    int out_type;                 // SGLK_OUT_*
+    int64_t out_stride;
+    int scatter;                  // 1: output row = slot (MoE down projection)
+    const float* topk_weights;    // GG_DOWN
+    const float* bias;            // [n_out] f32 or null
+    const void* addend;           // bf16 [rows][n_out] added as addend * addend_scale (shared expert) or null
+    int64_t addend_stride;
+    float addend_scale;
+};
+
+int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream);
+int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, hipStream_t stream);
+// per-row symmetric int8 quantisation: q = rint(x * 127/amax), scale = amax/127, amax = max(|row|, floor)
+int launch_quant_int8_rows(const uint16_t* x, int64_t x_stride, int8_t* q, int64_t q_stride, float* scale, int64_t rows,
+                           int cols, float floor, hipStream_t stream);
+
+int launch_quant_int8_rows_f32(const float* x, int64_t x_stride, int8_t* q, int64_t q_stride, float* scale,
+                               int64_t rows, int cols, float floor, hipStream_t stream);
+
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
                        int K, int E, int topk, hipStream_t stream);

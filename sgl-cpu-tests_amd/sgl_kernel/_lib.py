@@ -24,6 +24,36 @@ class FusedExpertsArgs(ctypes.Structure):
     ]
 
 
+class SharedExpertArgs(ctypes.Structure):
+    """Mirror of `sglk_shared_expert_args`."""
+    _fields_ = [
+        ("hidden", ctypes.c_void_p), ("hidden_stride", ctypes.c_int64),
+        ("out", ctypes.c_void_p), ("out_stride", ctypes.c_int64),
+        ("w1", ctypes.c_void_p), ("w2", ctypes.c_void_p),
+        ("w1_scale", ctypes.c_void_p), ("w2_scale", ctypes.c_void_p),
+        ("fused_out", ctypes.c_void_p), ("fused_out_stride", ctypes.c_int64),
+        ("routed_scaling_factor", ctypes.c_float),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("wtype", ctypes.c_int32), ("packed", ctypes.c_int32),
+        ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+class ScaledMmArgs(ctypes.Structure):
+    """Mirror of `sglk_scaled_mm_args`."""
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("x_stride", ctypes.c_int64), ("x_is_int8", ctypes.c_int32),
+        ("x_scale", ctypes.c_void_p), ("w", ctypes.c_void_p), ("w_scale", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out_stride", ctypes.c_int64),
+        ("out_type", ctypes.c_int32), ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("wtype", ctypes.c_int32), ("packed", ctypes.c_int32), ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
+OUT_BF16, OUT_F16, OUT_F32 = 0, 1, 2
+
 # symbol -> (restype, argtypes); every symbol include/sglk.h declares must be listed here
 # (tests/test_cabi_symbols.py checks the two against each other)
 _SIGNATURES = {
@@ -41,6 +71,12 @@ _SIGNATURES = {
     "sglk_moe_align": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "sglk_shared_expert_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 4),
+    "sglk_shared_expert": (ctypes.c_int, [ctypes.POINTER(SharedExpertArgs), ctypes.c_void_p]),
+    "sglk_scaled_mm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 5),
+    "sglk_scaled_mm": (ctypes.c_int, [ctypes.POINTER(ScaledMmArgs), ctypes.c_void_p]),
+    "sglk_per_token_quant_int8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_stage_timer_create": (ctypes.c_void_p, [ctypes.c_int32]),
     "sglk_stage_timer_destroy": (None, [ctypes.c_void_p]),
     "sglk_stage_timer_reset": (None, [ctypes.c_void_p]),

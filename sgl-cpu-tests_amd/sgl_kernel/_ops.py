@@ -63,8 +63,16 @@ _DEF.define("convert_weight_packed(Tensor weight) -> Tensor")
 
 
 def _pack_supported(rows, cols, dtype):
-    tc = 32 if dtype == torch.bfloat16 else 64
-    return rows % 16 == 0 and cols % tc == 0
+    if dtype == torch.bfloat16:
+        return rows % 32 == 0 and cols % 8 == 0
+    return rows % 16 == 0 and cols % 64 == 0
+
+
+def _packed_bits(is_vnni, shape1, shape2, dtype):
+    """bit 0: w1 is in packed order, bit 1: w2 is (a weight is re-tiled iff its own shape allows it)."""
+    if not is_vnni:
+        return 0
+    return (1 if _pack_supported(shape1[0], shape1[1], dtype) else 0) | (2 if _pack_supported(shape2[0], shape2[1], dtype) else 0)
 
 
 def convert_weight_packed(weight):
@@ -168,7 +176,7 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
         w2_scale=w2_scale.data_ptr() if w2_scale is not None else None,
         topk_weights=topk_weights.data_ptr(), topk_ids=topk_ids.data_ptr(),
         M=M, N=N, K=K, E=E, topk=topk, wtype=wtype,
-        packed=1 if (is_vnni and _pack_supported(2 * N, K, wdtype) and _pack_supported(K, N, wdtype)) else 0,
+        packed=_packed_bits(is_vnni, (2 * N, K), (K, N), wdtype),
         block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=_stage_timer)
     rc = L.sglk_fused_experts(ctypes.byref(args), _stream(hidden_states))
     _lib.check(rc, "fused_experts_cpu")
@@ -200,3 +208,167 @@ def _mut_inplace(a, args):
 
 _impl("fused_experts_cpu", fused_experts_cpu, _mut_inplace)
 _impl("fused_experts_cpu.method", fused_experts_cpu_method, _mut_inplace)
+
+
+# ------------------------------------------------------------------------------------------------------
+# shared_expert_cpu     14-arg: /root/reference/test_moe_fp8.py:87-88, test_moe_fp8_ext.py:60-61
+#                       12-arg: /root/reference/test_shared_experts.py:68,78
+# ------------------------------------------------------------------------------------------------------
+_DEF.define(
+    "shared_expert_cpu(Tensor(a!) hidden_states, Tensor w1, Tensor w2, Tensor fused_experts_out, "
+    "float routed_scaling_factor, bool inplace, bool use_int8_w8a8, bool use_fp8_w8a16, Tensor? w1_scale, "
+    "Tensor? w2_scale, int[]? block_size, Tensor? a1_scale, Tensor? a2_scale, bool is_vnni) -> Tensor")
+_DEF.define(
+    "shared_expert_cpu.v12(Tensor(a!) hidden_states, Tensor w1, Tensor w2, Tensor fused_experts_out, "
+    "float routed_scaling_factor, bool inplace, bool use_int8_w8a8, bool use_fp8_w8a16, Tensor? w1_scale, "
+    "Tensor? w2_scale, int[]? block_size, bool is_vnni) -> Tensor")
+
+
+def shared_expert_cpu(hidden_states, w1, w2, fused_experts_out, routed_scaling_factor, inplace, use_int8_w8a8,
+                      use_fp8_w8a16, w1_scale, w2_scale, block_size, a1_scale, a2_scale, is_vnni):
+    if use_int8_w8a8 and use_fp8_w8a16:
+        raise RuntimeError("shared_expert: use_int8_w8a8 and use_fp8_w8a16 are mutually exclusive")
+    if a1_scale is not None or a2_scale is not None:
+        raise RuntimeError("shared_expert: static activation scales are not supported")
+    if hidden_states.dim() != 2 or w1.dim() != 2 or w2.dim() != 2 or hidden_states.dtype != torch.bfloat16:
+        raise RuntimeError("shared_expert: expect bf16 hidden [M,K], w1 [2N,K], w2 [K,N]")
+    M, K = hidden_states.shape
+    N = w1.shape[0] // 2
+    if tuple(w1.shape) != (2 * N, K) or tuple(w2.shape) != (K, N) or tuple(fused_experts_out.shape) != (M, K):
+        raise RuntimeError("shared_expert: shape mismatch")
+    wdtype = torch.int8 if use_int8_w8a8 else (torch.float8_e4m3fn if use_fp8_w8a16 else torch.bfloat16)
+    if w1.dtype != wdtype or w2.dtype != wdtype:
+        raise RuntimeError(f"shared_expert: weights must be {wdtype} for this mode")
+    hs = hidden_states if hidden_states.stride(1) == 1 else hidden_states.contiguous()
+    fo = fused_experts_out.to(torch.bfloat16)
+    fo = fo if fo.stride(1) == 1 else fo.contiguous()
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    bn = bk = 0
+    if use_fp8_w8a16:
+        if block_size is None or len(block_size) != 2:
+            raise RuntimeError("shared_expert: fp8 needs block_size = [block_n, block_k]")
+        bn, bk = int(block_size[0]), int(block_size[1])
+    if wdtype != torch.bfloat16:
+        if w1_scale is None or w2_scale is None:
+            raise RuntimeError("shared_expert: quantised modes need w1_scale and w2_scale")
+        w1_scale = w1_scale.to(torch.float32).contiguous()
+        w2_scale = w2_scale.to(torch.float32).contiguous()
+    out = hs if (inplace and hs is hidden_states) else torch.empty_like(hs)
+    L = _lib.lib()
+    wtype = _WTYPE[wdtype]
+    ws_bytes = L.sglk_shared_expert_workspace_bytes(M, N, K, wtype)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=hs.device)
+    args = _lib.SharedExpertArgs(
+        hidden=hs.data_ptr(), hidden_stride=hs.stride(0), out=out.data_ptr(), out_stride=out.stride(0),
+        w1=w1.data_ptr(), w2=w2.data_ptr(),
+        w1_scale=w1_scale.data_ptr() if w1_scale is not None else None,
+        w2_scale=w2_scale.data_ptr() if w2_scale is not None else None,
+        fused_out=fo.data_ptr(), fused_out_stride=fo.stride(0), routed_scaling_factor=float(routed_scaling_factor),
+        M=M, N=N, K=K, wtype=wtype, packed=_packed_bits(is_vnni, (2 * N, K), (K, N), wdtype),
+        block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+    _lib.check(L.sglk_shared_expert(ctypes.byref(args), _stream(hs)), "shared_expert_cpu")
+    if inplace and out is not hidden_states:
+        hidden_states.copy_(out)
+        return hidden_states
+    return out
+
+
+def shared_expert_cpu_v12(hidden_states, w1, w2, fused_experts_out, routed_scaling_factor, inplace, use_int8_w8a8,
+                          use_fp8_w8a16, w1_scale, w2_scale, block_size, is_vnni):
+    return shared_expert_cpu(hidden_states, w1, w2, fused_experts_out, routed_scaling_factor, inplace, use_int8_w8a8,
+                             use_fp8_w8a16, w1_scale, w2_scale, block_size, None, None, is_vnni)
+
+
+_impl("shared_expert_cpu", shared_expert_cpu, _mut_inplace)
+_impl("shared_expert_cpu.v12", shared_expert_cpu_v12, _mut_inplace)
+
+# ------------------------------------------------------------------------------------------------------
+# dense GEMMs: weight_packed_linear (/root/reference/test_gemm.py:22-25), fp8_scaled_mm_cpu (test_gemm_fp8.py:54-62),
+# per_token_quant_int8_cpu / int8_scaled_mm_cpu / int8_scaled_mm_with_quant (test_gemm_int8.py:66-72)
+# ------------------------------------------------------------------------------------------------------
+_DEF.define("weight_packed_linear(Tensor x, Tensor weight, Tensor? bias, bool is_vnni) -> Tensor")
+_DEF.define("fp8_scaled_mm_cpu(Tensor mat1, Tensor mat2, Tensor scales2, int[] block_size, Tensor? bias, "
+            "ScalarType out_dtype, bool is_vnni) -> Tensor")
+_DEF.define("per_token_quant_int8_cpu(Tensor A) -> (Tensor, Tensor)")
+_DEF.define("int8_scaled_mm_cpu(Tensor mat1, Tensor mat2, Tensor scales1, Tensor scales2, Tensor? bias, "
+            "ScalarType out_dtype, bool is_vnni) -> Tensor")
+_DEF.define("int8_scaled_mm_with_quant(Tensor mat1, Tensor mat2, Tensor scales2, Tensor? bias, "
+            "ScalarType out_dtype, bool is_vnni) -> Tensor")
+
+_OUT_TYPE = {torch.bfloat16: _lib.OUT_BF16, torch.float16: _lib.OUT_F16, torch.float32: _lib.OUT_F32}
+
+
+def _scaled_mm(x, w, w_scale, bias, out_dtype, is_vnni, block, x_scale=None):
+    if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+        raise RuntimeError(f"scaled_mm: expect x [M,K], w [N,K] (got {tuple(x.shape)}, {tuple(w.shape)})")
+    if out_dtype not in _OUT_TYPE:
+        raise RuntimeError(f"scaled_mm: unsupported out_dtype {out_dtype}")
+    if w.dtype not in _WTYPE:
+        raise RuntimeError(f"scaled_mm: unsupported weight dtype {w.dtype}")
+    x_is_int8 = x.dtype == torch.int8
+    if not x_is_int8 and x.dtype != torch.bfloat16:
+        raise RuntimeError(f"scaled_mm: activations must be bfloat16 or int8 (got {x.dtype})")
+    M, K = x.shape
+    N = w.shape[0]
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    w = w.contiguous()
+    if w_scale is not None:
+        w_scale = w_scale.to(torch.float32).contiguous()
+    if bias is not None:
+        bias = bias.to(torch.float32).contiguous()
+    if x_scale is not None:
+        x_scale = x_scale.to(torch.float32).contiguous().view(-1)
+    out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    L = _lib.lib()
+    wtype = _WTYPE[w.dtype]
+    ws_bytes = L.sglk_scaled_mm_workspace_bytes(M, N, K, wtype, int(x_is_int8))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    args = _lib.ScaledMmArgs(
+        x=x.data_ptr(), x_stride=x.stride(0), x_is_int8=int(x_is_int8),
+        x_scale=x_scale.data_ptr() if x_scale is not None else None, w=w.data_ptr(),
+        w_scale=w_scale.data_ptr() if w_scale is not None else None,
+        bias=bias.data_ptr() if bias is not None else None, out=out.data_ptr(), out_stride=out.stride(0),
+        out_type=_OUT_TYPE[out_dtype], M=M, N=N, K=K, wtype=wtype,
+        packed=1 if (is_vnni and _pack_supported(N, K, w.dtype)) else 0,
+        block_n=int(block[0]) if block else 0, block_k=int(block[1]) if block else 0,
+        workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
+    _lib.check(L.sglk_scaled_mm(ctypes.byref(args), _stream(x)), "scaled_mm")
+    return out
+
+
+def weight_packed_linear(x, weight, bias, is_vnni):
+    return _scaled_mm(x, weight, None, bias, x.dtype, is_vnni, None)
+
+
+def fp8_scaled_mm_cpu(mat1, mat2, scales2, block_size, bias, out_dtype, is_vnni):
+    if len(block_size) != 2:
+        raise RuntimeError("fp8_scaled_mm: block_size must be [block_n, block_k]")
+    return _scaled_mm(mat1, mat2, scales2, bias, out_dtype, is_vnni, block_size)
+
+
+def per_token_quant_int8_cpu(A):
+    if A.dim() != 2 or A.dtype != torch.bfloat16:
+        raise RuntimeError("per_token_quant_int8: expect a 2-D bfloat16 tensor")
+    A = A if A.stride(1) == 1 else A.contiguous()
+    M, K = A.shape
+    q = torch.empty(M, K, dtype=torch.int8, device=A.device)
+    s = torch.empty(M, dtype=torch.float32, device=A.device)
+    _lib.check(_lib.lib().sglk_per_token_quant_int8(_ptr(A), A.stride(0), _ptr(q), K, _ptr(s), M, K, _stream(A)),
+               "per_token_quant_int8_cpu")
+    return q, s
+
+
+def int8_scaled_mm_cpu(mat1, mat2, scales1, scales2, bias, out_dtype, is_vnni):
+    return _scaled_mm(mat1, mat2, scales2, bias, out_dtype, is_vnni, None, x_scale=scales1)
+
+
+def int8_scaled_mm_with_quant(mat1, mat2, scales2, bias, out_dtype, is_vnni):
+    return _scaled_mm(mat1, mat2, scales2, bias, out_dtype, is_vnni, None)
+
+
+_impl("weight_packed_linear", weight_packed_linear)
+_impl("fp8_scaled_mm_cpu", fp8_scaled_mm_cpu)
+_impl("per_token_quant_int8_cpu", per_token_quant_int8_cpu)
+_impl("int8_scaled_mm_cpu", int8_scaled_mm_cpu)
+_impl("int8_scaled_mm_with_quant", int8_scaled_mm_with_quant)

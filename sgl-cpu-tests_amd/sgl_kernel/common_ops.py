@@ -6,3 +6,9 @@ from . import _ops  # noqa: F401
 
 convert_weight_packed = torch.ops.sgl_kernel.convert_weight_packed
 fused_experts_cpu = torch.ops.sgl_kernel.fused_experts_cpu
+shared_expert_cpu = torch.ops.sgl_kernel.shared_expert_cpu
+weight_packed_linear = torch.ops.sgl_kernel.weight_packed_linear
+fp8_scaled_mm_cpu = torch.ops.sgl_kernel.fp8_scaled_mm_cpu
+per_token_quant_int8_cpu = torch.ops.sgl_kernel.per_token_quant_int8_cpu
+int8_scaled_mm_cpu = torch.ops.sgl_kernel.int8_scaled_mm_cpu
+int8_scaled_mm_with_quant = torch.ops.sgl_kernel.int8_scaled_mm_with_quant

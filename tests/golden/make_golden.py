@@ -164,7 +164,65 @@ def gen_topk():
                                             biased=int(biased), seed=seed))
 
 
-FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk}
+def gen_gemm():
+    ns = lift("test_gemm_int8.py", ["per_token_quant_int8", "native_w8a8_per_token_matmul"])
+    for name, M, N, K, has_bias, seed in recipes.GEMM_INT8_CASES:
+        inp = recipes.gemm_int8_inputs(M, N, K, has_bias, seed)
+        Aq, As = ns["per_token_quant_int8"](inp["A"])
+        ref = ns["native_w8a8_per_token_matmul"](Aq, inp["Bq"], As, inp["Bs"], inp.get("bias"), torch.bfloat16)
+        save("gemm_int8_" + name, {"ref_out": ref, "ref_Aq": Aq, "ref_As": As.float().reshape(-1)},
+             dict(M=M, N=N, K=K, seed=seed, input_sha256=checksum(inp["A"], inp["Bq"], inp["Bs"])))
+    nsf = lift("test_gemm_fp8.py", ["scaled_weight"], {"BLOCK_N": 64, "BLOCK_K": 128})
+    for name, M, N, K, has_bias, chunk, seed in recipes.GEMM_FP8_CASES:
+        inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, chunk, seed)
+        # /root/reference/test_gemm_fp8.py:41-49 (inline): bf16 dequantised weight, bf16 matmul, bf16 bias add
+        ws = nsf["scaled_weight"](inp["w"], inp["scales"]).view(N, K).to(torch.bfloat16)
+        ref = torch.matmul(inp["data"].to(torch.bfloat16), ws.T)
+        if has_bias:
+            ref = ref + inp["bias"].to(torch.bfloat16)
+        # and the fp32 formulation of the same product (what the implementation is held to more tightly)
+        ref32 = inp["data"].float() @ nsf["scaled_weight"](inp["w"], inp["scales"]).view(N, K).T
+        if has_bias:
+            ref32 = ref32 + inp["bias"]
+        save("gemm_fp8_" + name, {"ref_out_bf16": ref, "ref_out_f32": ref32},
+             dict(M=M, N=N, K=K, seed=seed, input_sha256=checksum(inp["data"].contiguous(), inp["w"], inp["scales"])))
+    for name, M, N, K, has_bias, seed in recipes.GEMM_BF16_CASES:
+        inp = recipes.gemm_bf16_inputs(M, N, K, has_bias, seed)
+        # /root/reference/test_gemm.py:15-20 (inline)
+        ref = torch.matmul(inp["mat1"].float(), inp["mat2"].float().t())
+        if has_bias:
+            ref.add_(inp["bias"].bfloat16())
+        save("gemm_bf16_" + name, {"ref_out": ref.bfloat16()},
+             dict(M=M, N=N, K=K, seed=seed, input_sha256=checksum(inp["mat1"], inp["mat2"])))
+
+
+def gen_shared():
+    ns = lift("test_shared_experts.py", ["SiluAndMul", "per_token_quant_int8", "native_w8a8_per_token_matmul",
+                                         "torch_naive_moe", "torch_w8a8_per_column_moe"])
+    for name, m, n, k, rsf, seed in recipes.SHARED_CASES:
+        inp = recipes.shared_inputs(m, n, k, seed)
+        ref = ns["torch_naive_moe"](inp["hs"].float(), inp["w1"].float(), inp["w2"].float(), inp["fused"].float(), rsf)
+        w1q, w1s = ns["per_token_quant_int8"](inp["w1"])
+        w2q, w2s = ns["per_token_quant_int8"](inp["w2"])
+        ref8 = ns["torch_w8a8_per_column_moe"](inp["hs"].float(), w1q, w2q, w1s, w2s, inp["fused"].float(), rsf)
+        save("shared_" + name, {"ref_bf16": ref.bfloat16(), "ref_int8": ref8.bfloat16(), "w1q": w1q, "w2q": w2q,
+                                "w1s": w1s.float().reshape(-1), "w2s": w2s.float().reshape(-1)},
+             dict(m=m, n=n, k=k, rsf=rsf, seed=seed, input_sha256=checksum(inp["hs"], inp["w1"], inp["w2"], inp["fused"])))
+    nsf = lift("test_moe_fp8_ext.py", ["SiluAndMul", "scaled_weight"], {"BLOCK_N": 64, "BLOCK_K": 128})
+    for name, M, N, K, rsf, seed in recipes.SHARED_FP8_CASES:
+        inp = recipes.shared_fp8_inputs(M, N, K, seed)
+        # /root/reference/test_moe_fp8_ext.py:39-56 (inline, fp32)
+        w1sc = nsf["scaled_weight"](inp["w1"][None], inp["w1s"][None]).view(2 * N, K)
+        w2sc = nsf["scaled_weight"](inp["w2"][None], inp["w2s"][None]).view(K, N)
+        ic1 = nsf["SiluAndMul"](torch.matmul(inp["a"].float(), w1sc.transpose(0, 1)))
+        ref = torch.matmul(ic1, w2sc.transpose(0, 1)) + inp["fused"].float() * rsf
+        save("shared_fp8_" + name, {"ref_out_f32": ref},
+             dict(M=M, N=N, K=K, rsf=rsf, seed=seed,
+                  input_sha256=checksum(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["fused"])))
+
+
+FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
+            "shared": gen_shared}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(FAMILIES)

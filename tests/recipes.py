@@ -130,3 +130,90 @@ def topk_inputs(M, E, biased, seed):
     if biased:
         d["bias"] = torch.randn(E, generator=g).to(torch.bfloat16)
     return d
+
+
+# ---- dense GEMMs ---------------------------------------------------------------------------------------------------
+# name, M, N, K, has_bias, seed           int8 w8a8 per-token / per-channel (/root/reference/test_gemm_int8.py:75-78)
+GEMM_INT8_CASES = [
+    ("m128_n384_k544_bias", 128, 384, 544, True, 4111),
+    ("m2_n32_k32", 2, 32, 32, False, 4112),
+    ("m300_n1536_k2048", 300, 1536, 2048, False, 4113),     # Qwen3 expert gate_up as a dense shape
+]
+# name, M, N, K, has_bias, chunk(row-strided mat1), seed     fp8 block [64,128] (/root/reference/test_gemm_fp8.py:109-122)
+GEMM_FP8_CASES = [
+    ("m1_n128_k512_bias", 1, 128, 512, True, False, 4211),
+    ("m111_n192_k640", 111, 192, 640, False, False, 4212),
+    ("m14_n192_k768_bias_chunk", 14, 192, 768, True, True, 4213),
+    ("m64_n2816_k1024_bias", 64, 2816, 1024, True, False, 4214),
+]
+# name, M, N, K, has_bias, seed           bf16 weight_packed_linear (/root/reference/test_gemm.py:30-33)
+GEMM_BF16_CASES = [
+    ("m1_n416_k512_bias", 1, 416, 512, True, 4311),
+    ("m11_n416_k512_bias", 11, 416, 512, True, 4312),
+    ("m128_n4096_k4096", 128, 4096, 4096, False, 4313),     # BASELINE.json config 0
+]
+# name, m, n, k, rsf, seed                shared expert bf16 + int8 (/root/reference/test_shared_experts.py:85-87)
+SHARED_CASES = [
+    ("m2_n32_k32", 2, 32, 32, 16.0, 5111),
+    ("m121_n128_k64", 121, 128, 64, 16.0, 5112),
+]
+# name, M, N, K, rsf, seed                shared expert fp8 block [64,128] (/root/reference/test_moe_fp8_ext.py:65-67)
+SHARED_FP8_CASES = [
+    ("m2_n256_k1024", 2, 256, 1024, 16.0, 5211),
+    ("m12_n128_k256", 12, 128, 256, 16.0, 5212),
+    ("m1212_n128_k256", 1212, 128, 256, 16.0, 5213),
+]
+
+
+def gemm_int8_inputs(M, N, K, has_bias, seed):
+    g = _gen(seed)
+    A = (torch.randn(M, K, generator=g) / 10).to(torch.bfloat16)
+    B = (torch.rand(N, K, generator=g) - 0.5) * 2
+    Bq = (B * 127).clamp(-128, 127).to(torch.int8)
+    Bs = torch.rand(N, generator=g) * 1e-2
+    d = dict(A=A, Bq=Bq, Bs=Bs)
+    if has_bias:
+        d["bias"] = torch.randn(N, generator=g)
+    return d
+
+
+def gemm_fp8_inputs(M, N, K, has_bias, chunk, seed, bn=64, bk=128):
+    g = _gen(seed)
+    if chunk:
+        data = torch.randn(M, K + 6, generator=g).to(torch.bfloat16).narrow(1, 0, K)
+    else:
+        data = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    data = data / math.sqrt(K)
+    w = fp8_weight((N, K), g)
+    scales = torch.randn(N // bn, K // bk, generator=g) * SCALE_FACTOR
+    d = dict(data=data, w=w, scales=scales)
+    if has_bias:
+        d["bias"] = torch.randn(N, generator=g)
+    return d
+
+
+def gemm_bf16_inputs(M, N, K, has_bias, seed):
+    g = _gen(seed)
+    d = dict(mat1=torch.randn(M, K, generator=g).to(torch.bfloat16), mat2=torch.randn(N, K, generator=g).to(torch.bfloat16))
+    if has_bias:
+        d["bias"] = torch.randn(N, generator=g)
+    return d
+
+
+def shared_inputs(m, n, k, seed):
+    """/root/reference/test_shared_experts.py:57-60."""
+    g = _gen(seed)
+    return dict(hs=(torch.randn(m, k, generator=g) / k).to(torch.bfloat16),
+                w1=torch.randn(2 * n, k, generator=g).to(torch.bfloat16),
+                w2=torch.randn(k, n, generator=g).to(torch.bfloat16),
+                fused=(torch.randn(m, k, generator=g) / k).to(torch.bfloat16))
+
+
+def shared_fp8_inputs(M, N, K, seed, bn=64, bk=128):
+    """/root/reference/test_moe_fp8_ext.py:27-49."""
+    g = _gen(seed)
+    return dict(a=(torch.randn(M, K, generator=g) / math.sqrt(K)).to(torch.bfloat16),
+                w1=fp8_weight((2 * N, K), g), w2=fp8_weight((K, N), g),
+                w1s=torch.randn(2 * N // bn, K // bk, generator=g) * SCALE_FACTOR,
+                w2s=torch.randn(K // bn, N // bk, generator=g) * SCALE_FACTOR,
+                fused=(torch.randn(M, K, generator=g) / math.sqrt(K)).to(torch.bfloat16))

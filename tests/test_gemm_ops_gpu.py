@@ -1,0 +1,177 @@
+"""GPU parity of the GEMM-shaped operators on the generic engine, through torch.ops.sgl_kernel -> C-ABI -> HIP:
+bf16 / int8 fused_experts (/root/reference/test_moe.py, test_moe_int8.py), shared_expert (test_shared_experts.py,
+test_moe_fp8_ext.py:27-67), weight_packed_linear / fp8_scaled_mm / int8_scaled_mm (test_gemm*.py).
+Expected values: tests/golden (the reference's own oracles run in the build container)."""
+import pytest
+import torch
+
+import recipes
+from conftest import load_golden
+from oracle import gemm as ogemm
+from oracle import moe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sgl_kernel  # noqa: F401
+    assert torch.cuda.is_available()
+    return torch.ops.sgl_kernel
+
+
+def cuda(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+def ref_pred(ref, out):
+    """utils.compare's predicate (/root/reference/utils.py:9-13) on bf16."""
+    return torch.allclose(ref.bfloat16().cpu(), out.bfloat16().cpu(), rtol=1e-2, atol=1e-2)
+
+
+def rel_rms(out, ref):
+    return float((out.float().cpu() - ref.float().cpu()).norm() / ref.float().cpu().norm().clamp_min(1e-12))
+
+
+# ---- fused_experts bf16 / int8 ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prepack", [False, True])
+@pytest.mark.parametrize("case", recipes.MOE_BF16_CASES, ids=lambda c: c[0])
+def test_fused_experts_bf16(ops, case, prepack):
+    from sglang.srt.layers.amx_utils import CPUQuantMethod
+    name, M, N, K, E, topk, renorm, seed, full = case
+    g, _ = load_golden("moe_bf16_" + name)
+    inp = cuda(recipes.moe_bf16_inputs(M, N, K, E, topk, seed))
+    w, ids = moe.softmax_topk(inp["score"].cpu(), topk, renorm)
+    w1 = ops.convert_weight_packed(inp["w1"]) if prepack else inp["w1"]
+    w2 = ops.convert_weight_packed(inp["w2"]) if prepack else inp["w2"]
+    a = inp["a"].clone()
+    # 13-argument CPUQuantMethod form, inplace=True, exactly as /root/reference/test_moe.py:79-92
+    out = ops.fused_experts_cpu(a, w1, w2, w.cuda(), ids.cuda(), True, CPUQuantMethod.UNQUANT, None, None, None, None,
+                                None, prepack)
+    assert out.data_ptr() == a.data_ptr()
+    assert ref_pred(g["ref_out"], out), name
+    ref32 = moe.fused_experts_f32(inp["a"].cpu(), inp["w1"].cpu().float(), inp["w2"].cpu().float(), w, ids)
+    assert rel_rms(out, ref32) < 6e-3
+
+
+@pytest.mark.parametrize("prepack", [False, True])
+@pytest.mark.parametrize("case", recipes.MOE_INT8_CASES, ids=lambda c: c[0])
+def test_fused_experts_int8(ops, case, prepack):
+    name, M, N, K, E, topk, seed, full = case
+    g, _ = load_golden("moe_int8_" + name)
+    inp = cuda(recipes.moe_int8_inputs(M, N, K, E, topk, seed))
+    w1 = ops.convert_weight_packed(inp["w1"]) if prepack else inp["w1"]
+    w2 = ops.convert_weight_packed(inp["w2"]) if prepack else inp["w2"]
+    out = ops.fused_experts_cpu(inp["a"].clone(), w1, w2, inp["topk_weight"], inp["topk_ids"], True, True, False,
+                                inp["w1s"], inp["w2s"], None, None, None, prepack)
+    ref = g["ref_out"].float()
+    # the reference's real bar for int8 (test_moe_int8.py:134-137): mean relative error < 1 %
+    mre = (out.float().cpu() - ref).abs().mean() / ref.abs().mean()
+    assert mre < 0.01, f"{name}: mean relative error {mre:.4f}"
+    assert ref_pred(ref, out), name
+
+
+# ---- shared_expert ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", recipes.SHARED_CASES, ids=lambda c: c[0])
+def test_shared_expert_bf16_and_int8(ops, case):
+    name, m, n, k, rsf, seed = case
+    g, _ = load_golden("shared_" + name)
+    inp = cuda(recipes.shared_inputs(m, n, k, seed))
+    hs = inp["hs"].clone()
+    # 12-argument form of /root/reference/test_shared_experts.py:68
+    res = ops.shared_expert_cpu(hs, inp["w1"], inp["w2"], inp["fused"], rsf, True, False, False, None, None, None, False)
+    assert res.data_ptr() == hs.data_ptr() and ref_pred(g["ref_bf16"], res), name
+    hs2 = inp["hs"].clone()
+    res8 = ops.shared_expert_cpu(hs2, g["w1q"].cuda(), g["w2q"].cuda(), inp["fused"], rsf, True, True, False,
+                                 g["w1s"].cuda(), g["w2s"].cuda(), None, False)
+    assert ref_pred(g["ref_int8"], res8), name
+
+
+@pytest.mark.parametrize("prepack", [False, True])
+@pytest.mark.parametrize("case", recipes.SHARED_FP8_CASES, ids=lambda c: c[0])
+def test_shared_expert_fp8(ops, case, prepack):
+    name, M, N, K, rsf, seed = case
+    g, _ = load_golden("shared_fp8_" + name)
+    inp = cuda(recipes.shared_fp8_inputs(M, N, K, seed))
+    w1 = ops.convert_weight_packed(inp["w1"]) if prepack else inp["w1"]
+    w2 = ops.convert_weight_packed(inp["w2"]) if prepack else inp["w2"]
+    a2 = inp["a"].clone()
+    # 14-argument form of /root/reference/test_moe_fp8_ext.py:60-61
+    out = ops.shared_expert_cpu(a2, w1, w2, inp["fused"], rsf, True, False, True, inp["w1s"], inp["w2s"], [64, 128],
+                                None, None, prepack)
+    assert ref_pred(g["ref_out_f32"], out), name
+    assert rel_rms(out, g["ref_out_f32"]) < 6e-3
+
+
+# ---- dense GEMMs -----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prepack", [False, True])
+@pytest.mark.parametrize("case", recipes.GEMM_BF16_CASES, ids=lambda c: c[0])
+def test_weight_packed_linear(ops, case, prepack):
+    name, M, N, K, has_bias, seed = case
+    g, _ = load_golden("gemm_bf16_" + name)
+    inp = cuda(recipes.gemm_bf16_inputs(M, N, K, has_bias, seed))
+    w = ops.convert_weight_packed(inp["mat2"]) if prepack else inp["mat2"]
+    out = ops.weight_packed_linear(inp["mat1"], w, inp.get("bias"), prepack)
+    assert out.dtype == torch.bfloat16 and ref_pred(g["ref_out"], out), name
+
+
+def test_bf16_prepack_matches_reference_layout(ops):
+    """The one layout the reference pins with a live known-answer test (/root/reference/test_gemm.py:36-46)."""
+    oc, ic = 16 * 8, 32 * 24
+    w1 = torch.randn(oc, ic, device="cuda").bfloat16()
+    packed = ops.convert_weight_packed(w1)
+    ref = w1.view(oc // 32, 32, ic // 2, 2).permute(0, 2, 1, 3).contiguous().view(oc, ic)
+    assert torch.equal(ref, packed)
+
+
+@pytest.mark.parametrize("prepack", [False, True])
+@pytest.mark.parametrize("case", recipes.GEMM_FP8_CASES, ids=lambda c: c[0])
+def test_fp8_scaled_mm(ops, case, prepack):
+    name, M, N, K, has_bias, chunk, seed = case
+    g, _ = load_golden("gemm_fp8_" + name)
+    inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, chunk, seed)
+    data = inp["data"].cuda() if not chunk else torch.empty(M, K + 6, dtype=torch.bfloat16, device="cuda").narrow(1, 0, K).copy_(inp["data"])
+    assert (data.stride(0) != K) == chunk
+    w = inp["w"].cuda()
+    w = ops.convert_weight_packed(w) if prepack else w
+    bias = inp["bias"].cuda() if has_bias else None
+    out = ops.fp8_scaled_mm_cpu(data, w, inp["scales"].cuda(), [64, 128], bias, data.dtype, prepack)
+    assert ref_pred(g["ref_out_bf16"], out), name          # the reference's own (bf16) oracle
+    assert rel_rms(out, g["ref_out_f32"]) < 4e-3
+    out32 = ops.fp8_scaled_mm_cpu(data, w, inp["scales"].cuda(), [64, 128], bias, torch.float32, prepack)
+    torch.testing.assert_close(out32.cpu(), g["ref_out_f32"], rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("case", recipes.GEMM_INT8_CASES, ids=lambda c: c[0])
+def test_int8_gemm_ops(ops, case):
+    name, M, N, K, has_bias, seed = case
+    g, _ = load_golden("gemm_int8_" + name)
+    inp = cuda(recipes.gemm_int8_inputs(M, N, K, has_bias, seed))
+    Aq, As = ops.per_token_quant_int8_cpu(inp["A"])
+    assert torch.equal(Aq.cpu(), g["ref_Aq"]), "per-token int8 quantisation must be bit-exact"
+    assert torch.equal(As.cpu(), g["ref_As"])
+    bias = inp.get("bias")
+    out = ops.int8_scaled_mm_cpu(Aq, inp["Bq"], As, inp["Bs"], bias, torch.bfloat16, False)
+    assert ref_pred(g["ref_out"], out), name
+    fused = ops.int8_scaled_mm_with_quant(inp["A"], inp["Bq"], inp["Bs"], bias, torch.bfloat16, False)
+    assert torch.equal(fused, out), "fused quant+mm must equal the two-step path bit for bit"
+    if N % 16 == 0 and K % 64 == 0:
+        outp = ops.int8_scaled_mm_cpu(Aq, ops.convert_weight_packed(inp["Bq"]), As, inp["Bs"], bias, torch.bfloat16, True)
+        assert torch.equal(outp, out)
+
+
+def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):
+    """Same fp8 fused_experts inputs through the tuned path and (forced) through the generic engine."""
+    name, M, N, K, E, topk, bn, bk, masked, seed, full = recipes.MOE_FP8_CASES[1]
+    g, _ = load_golden("moe_fp8_" + name)
+    inp = cuda(recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed))
+    w1p, w2p = ops.convert_weight_packed(inp["w1"]), ops.convert_weight_packed(inp["w2"])
+    args = (inp["topk_weight"], inp["topk_ids"], False, False, True, inp["w1s"], inp["w2s"], [bn, bk], None, None)
+    tuned = ops.fused_experts_cpu(inp["a"], w1p, w2p, *args, True)
+    monkeypatch.setenv("SGLK_FORCE_GENERIC", "1")
+    generic_packed = ops.fused_experts_cpu(inp["a"], w1p, w2p, *args, True)
+    generic_plain = ops.fused_experts_cpu(inp["a"], inp["w1"], inp["w2"], *args, False)     # is_vnni=False
+    assert torch.equal(generic_packed, generic_plain)
+    for o in (tuned, generic_packed):
+        assert ref_pred(g["ref_out_f32"], o)
+    assert rel_rms(tuned, generic_packed) < 5e-3

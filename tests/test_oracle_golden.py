@@ -89,3 +89,66 @@ def test_torch_oracle_bf16_matches_reference(case):
     # the reference's bf16 oracle (test_moe.py:22-54) computes in bf16 end to end; ours in fp32:
     # they agree to the reference's own bf16 tolerance
     assert moe.allclose_ref(g["ref_out"], out.bfloat16())
+
+
+# ---- dense GEMMs and shared expert ---------------------------------------------------------------------------------
+from oracle import gemm as ogemm  # noqa: E402
+
+
+@pytest.mark.parametrize("case", recipes.GEMM_INT8_CASES, ids=lambda c: c[0])
+def test_oracle_gemm_int8(case):
+    name, M, N, K, has_bias, seed = case
+    g, meta = load_golden("gemm_int8_" + name)
+    inp = recipes.gemm_int8_inputs(M, N, K, has_bias, seed)
+    assert _sha(inp["A"], inp["Bq"], inp["Bs"]) == meta["input_sha256"]
+    q, s = ogemm.per_token_quant_int8(inp["A"])
+    assert torch.equal(q, g["ref_Aq"]) and torch.equal(s, g["ref_As"])          # integer work: bit-exact
+    out = ogemm.int8_scaled_mm(q, s, inp["Bq"], inp["Bs"], inp.get("bias"))
+    assert moe.allclose_ref(g["ref_out"], out.bfloat16())
+
+
+@pytest.mark.parametrize("case", recipes.GEMM_FP8_CASES, ids=lambda c: c[0])
+def test_oracle_gemm_fp8(case):
+    name, M, N, K, has_bias, chunk, seed = case
+    g, meta = load_golden("gemm_fp8_" + name)
+    inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, chunk, seed)
+    assert _sha(inp["data"].contiguous(), inp["w"], inp["scales"]) == meta["input_sha256"]
+    out = ogemm.fp8_scaled_mm(inp["data"], inp["w"], inp["scales"], (64, 128), inp.get("bias"))
+    torch.testing.assert_close(out, g["ref_out_f32"], rtol=1e-4, atol=1e-5)
+    assert moe.allclose_ref(g["ref_out_bf16"], out.bfloat16())                  # the reference's own bf16 oracle
+
+
+@pytest.mark.parametrize("case", recipes.GEMM_BF16_CASES, ids=lambda c: c[0])
+def test_oracle_gemm_bf16(case):
+    name, M, N, K, has_bias, seed = case
+    g, meta = load_golden("gemm_bf16_" + name)
+    inp = recipes.gemm_bf16_inputs(M, N, K, has_bias, seed)
+    assert _sha(inp["mat1"], inp["mat2"]) == meta["input_sha256"]
+    out = ogemm.linear_bf16(inp["mat1"], inp["mat2"], inp.get("bias"))
+    assert torch.equal(out.bfloat16(), g["ref_out"])
+
+
+@pytest.mark.parametrize("case", recipes.SHARED_CASES, ids=lambda c: c[0])
+def test_oracle_shared_expert(case):
+    name, m, n, k, rsf, seed = case
+    g, meta = load_golden("shared_" + name)
+    inp = recipes.shared_inputs(m, n, k, seed)
+    assert _sha(inp["hs"], inp["w1"], inp["w2"], inp["fused"]) == meta["input_sha256"]
+    out = moe.shared_expert_f32(inp["hs"], inp["w1"], inp["w2"], inp["fused"], rsf)
+    assert moe.allclose_ref(g["ref_bf16"], out.bfloat16())
+    w1q, w1s = moe.quant_int8_rowwise(inp["w1"])
+    assert torch.equal(w1q, g["w1q"])
+    out8 = moe.shared_expert_int8(inp["hs"], g["w1q"], g["w2q"], g["w1s"], g["w2s"], inp["fused"], rsf)
+    assert moe.allclose_ref(g["ref_int8"], out8.bfloat16())
+
+
+@pytest.mark.parametrize("case", recipes.SHARED_FP8_CASES, ids=lambda c: c[0])
+def test_oracle_shared_expert_fp8(case):
+    name, M, N, K, rsf, seed = case
+    g, meta = load_golden("shared_fp8_" + name)
+    inp = recipes.shared_fp8_inputs(M, N, K, seed)
+    assert _sha(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["fused"]) == meta["input_sha256"]
+    w1 = moe.dequant_block_fp8(inp["w1"], inp["w1s"], 64, 128)
+    w2 = moe.dequant_block_fp8(inp["w2"], inp["w2s"], 64, 128)
+    out = moe.shared_expert_f32(inp["a"], w1, w2, inp["fused"], rsf)
+    torch.testing.assert_close(out, g["ref_out_f32"], rtol=1e-4, atol=1e-5)
