@@ -177,6 +177,31 @@ int sglk_per_token_quant_int8(const void* x, int64_t x_stride, void* q, int64_t 
                               int64_t rows, int32_t cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Row kernels (bf16 or fp16 I/O selected by is_f16; strides in elements)
+ *   silu_and_mul        out[r][c] = silu(x[r][c]) * x[r][d+c]      /root/reference/test_activation.py:14-28,
+ *                                                                  bench_silu_and_mul.py:31
+ *   rmsnorm             out = rmsnorm(x) * weight                   /root/reference/test_norm.py:43-47
+ *   fused_add_rmsnorm   residual <- x + residual; x <- rmsnorm(residual) * weight (both in place)   test_norm.py:52-59
+ * --------------------------------------------------------------------------------------------------------- */
+int sglk_silu_and_mul(const void* x, int64_t x_stride, void* out, int64_t out_stride, int64_t rows, int32_t d,
+                      int32_t is_f16, void* stream);
+int sglk_rmsnorm(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* weight, int64_t rows,
+                 int32_t hidden, float eps, int32_t is_f16, void* stream);
+int sglk_fused_add_rmsnorm(void* x, int64_t x_stride, void* residual, int64_t res_stride, const void* weight,
+                           int64_t rows, int32_t hidden, float eps, int32_t is_f16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * grouped_topk / biased_grouped_topk   /root/reference/test_grouped_topk.py:61-69, test_moe.py:61-70,
+ *                                      test_biased_grouped_topk.py:71-80
+ * gating [M][E] (gating_type 0 bf16, 1 f16, 2 f32); bias [E] of the same type or NULL (NULL = softmax scoring,
+ * else sigmoid + bias with top-2-sum group scores).  Writes topk_weights [M][topk] f32 and topk_ids [M][topk] i32
+ * in descending order of the selection score; ties -> lower expert index.
+ * --------------------------------------------------------------------------------------------------------- */
+int sglk_grouped_topk(const void* gating, int64_t gating_stride, int32_t gating_type, const void* bias,
+                      float* topk_weights, int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t renormalize,
+                      int32_t num_expert_group, int32_t topk_group, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Stages of fused_experts exposed for tests and profiling (same kernels the fused call launches).
  * moe_align: counting sort of the M*topk slots by expert (ids outside [0,E) dropped), stable in slot order.
  *   sorted_slot [M*topk] i32   slot = m*topk + j, grouped by expert

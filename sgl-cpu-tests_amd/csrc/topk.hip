@@ -1,0 +1,211 @@
+// DeepSeek-style grouped expert routing: grouped_topk (softmax) and biased_grouped_topk (sigmoid + correction bias).
+//
+// Oracles: /root/reference/test_grouped_topk.py:9-39 and /root/reference/test_biased_grouped_topk.py:9-47:
+//   scores = softmax(gating) | sigmoid(gating);  choice = scores (| + bias)
+//   group score = max of the group's scores | sum of the group's two largest choices
+//   keep the topk_group best groups, take the topk best experts among them by `choice`,
+//   weights = scores at those ids, optionally renormalised to sum 1.
+// One wave per token, everything in fp32.  Tie rule (the reference's torch.topk leaves it open): larger value
+// first, equal values -> lower index first; experts of non-selected groups are only taken when the selected groups
+// hold fewer than topk experts, and then carry weight 0 (softmax variant, matching masked_fill(0.0)).
+// Output order: descending choice.  Integer results are compared bit-exactly against this repo's oracle.
+#include "sglk_common.h"
+
+namespace sglk {
+
+constexpr int kTopkMaxE = 1024;   // experts per token: 16 per lane
+constexpr int kPerLane = kTopkMaxE / 64;
+
+SGLK_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+SGLK_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// arg-max over the wave of (value, index): larger value wins, ties -> lower index
+SGLK_DEV void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+template <int GT>   // gating element type: 0 bf16, 1 f16, 2 f32
+SGLK_DEV float ld_gate(const void* p, int64_t idx) {
+    if (GT == 2) return reinterpret_cast<const float*>(p)[idx];
+    const unsigned short b = reinterpret_cast<const unsigned short*>(p)[idx];
+    if (GT == 1) return (float)__builtin_bit_cast(_Float16, b);
+    return bf16_bits_to_f32(b);
+}
+
+template <int GT, bool BIASED>
+__global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restrict__ gating, int64_t g_stride,
+                                                           const void* __restrict__ bias, float* __restrict__ out_w,
+                                                           int* __restrict__ out_ids, int M, int E, int topk,
+                                                           int renormalize, int G, int topk_group) {
+    __shared__ float s_choice[4][kTopkMaxE];
+    __shared__ float s_gscore[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;   // whole wave; no block-level barrier is used below
+    float* choice_l = s_choice[wave];
+    float* gscore_l = s_gscore[wave];
+    const int per_group = E / G;
+
+    // ---- scores ---------------------------------------------------------------------------------------------------
+    float score[kPerLane], choice[kPerLane];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+        const int e = j * 64 + lane;
+        score[j] = e < E ? ld_gate<GT>(gating, (int64_t)m * g_stride + e) : -INFINITY;
+        mx = fmaxf(mx, score[j]);
+    }
+    if (!BIASED) {
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            score[j] = (j * 64 + lane < E) ? expf(score[j] - mx) : 0.f;
+            sum += score[j];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) { score[j] /= sum; choice[j] = score[j]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            const int e = j * 64 + lane;
+            if (e < E) {
+                score[j] = 1.0f / (1.0f + expf(-score[j]));
+                choice[j] = score[j] + ld_gate<GT>(bias, e);
+            } else {
+                score[j] = 0.f;
+                choice[j] = -INFINITY;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j)
+        if (j * 64 + lane < E) choice_l[j * 64 + lane] = choice[j];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    // ---- group scores, one lane per group (G <= 64) ------------------------------------------------------------------
+    float gs = -INFINITY;
+    if (lane < G) {
+        float a = -INFINITY, b = -INFINITY;   // two largest of the group
+        for (int i = 0; i < per_group; ++i) {
+            const float v = choice_l[lane * per_group + i];
+            if (v > a) { b = a; a = v; } else if (v > b) { b = v; }
+        }
+        gs = BIASED ? a + b : a;
+    }
+    // ---- the topk_group best groups -> bitmask ----------------------------------------------------------------------------
+    unsigned long long gmask = 0ull;
+    for (int r = 0; r < topk_group; ++r) {
+        float v = (lane < G && !((gmask >> lane) & 1ull)) ? gs : -INFINITY;
+        int i = lane;
+        // -inf group scores (NaN-free inputs only produce them for padding lanes) still need a deterministic pick
+        if (lane >= G || ((gmask >> lane) & 1ull)) i = 1 << 20;
+        wave_argmax(v, i);
+        if (i < G) gmask |= 1ull << i;
+    }
+    // ---- topk experts among the selected groups --------------------------------------------------------------------------
+    float masked[kPerLane];
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+        const int e = j * 64 + lane;
+        const bool in = e < E && ((gmask >> (e / per_group)) & 1ull);
+        masked[j] = in ? choice[j] : -INFINITY;
+    }
+    float wsum = 0.f;
+    float my_w = 0.f;
+    int my_id = 0;
+    for (int r = 0; r < topk; ++r) {
+        float bv = -INFINITY;
+        int bi = 1 << 20;
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            const int e = j * 64 + lane;
+            // only live candidates (> -inf); equal values -> lower index
+            if (e < E && masked[j] > -INFINITY && (masked[j] > bv || (masked[j] == bv && e < bi))) { bv = masked[j]; bi = e; }
+        }
+        // second chance: nothing left in the selected groups -> lowest-index expert not taken yet (weight 0 / raw score)
+        float v = bv;
+        int i = bi;
+        wave_argmax(v, i);
+        float w_sel = 0.f;
+        if (i >= E) {   // all remaining candidates are -inf: take the lowest index still marked "not taken"
+            int cand = 1 << 20;
+#pragma unroll
+            for (int j = 0; j < kPerLane; ++j) {
+                const int e = j * 64 + lane;
+                if (e < E && masked[j] == -INFINITY && choice[j] != INFINITY && e < cand) cand = e;   // choice==INF marks taken
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int oc = __shfl_xor(cand, o); cand = oc < cand ? oc : cand; }
+            i = cand < E ? cand : 0;
+        }
+        // owner lane retires the pick and supplies its (unbiased) score
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j) {
+            if (j * 64 + lane == i) {
+                const bool was_selected_group = masked[j] != -INFINITY;
+                w_sel = (BIASED || was_selected_group) ? score[j] : 0.f;
+                masked[j] = -INFINITY;
+                choice[j] = INFINITY;   // taken
+            }
+        }
+        w_sel = wave_sum(w_sel);
+        wsum += w_sel;
+        if (lane == r) { my_w = w_sel; my_id = i; }
+    }
+    if (lane < topk) {
+        out_ids[(int64_t)m * topk + lane] = my_id;
+        out_w[(int64_t)m * topk + lane] = renormalize ? my_w / wsum : my_w;
+    }
+}
+
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" int sglk_grouped_topk(const void* gating, int64_t gating_stride, int32_t gating_type, const void* bias,
+                                 float* topk_weights, int32_t* topk_ids, int32_t M, int32_t E, int32_t topk,
+                                 int32_t renormalize, int32_t num_expert_group, int32_t topk_group, void* stream) {
+    SGLK_REQUIRE(M >= 0 && E > 0 && topk > 0, SGLK_ERR_INVALID, "grouped_topk: bad sizes M=%d E=%d topk=%d", M, E, topk);
+    SGLK_REQUIRE(E <= kTopkMaxE, SGLK_ERR_SHAPE, "grouped_topk: at most %d experts (got %d)", kTopkMaxE, E);
+    SGLK_REQUIRE(topk <= 64 && topk <= E, SGLK_ERR_SHAPE, "grouped_topk: topk must be <= min(64, E) (got %d)", topk);
+    SGLK_REQUIRE(num_expert_group > 0 && num_expert_group <= 64 && E % num_expert_group == 0, SGLK_ERR_SHAPE,
+                 "grouped_topk: num_expert_group (%d) must divide E (%d) and be <= 64", num_expert_group, E);
+    SGLK_REQUIRE(topk_group > 0 && topk_group <= num_expert_group, SGLK_ERR_SHAPE,
+                 "grouped_topk: topk_group (%d) must be in [1, num_expert_group]", topk_group);
+    SGLK_REQUIRE(gating_type >= 0 && gating_type <= 2, SGLK_ERR_INVALID, "grouped_topk: bad gating_type");
+    SGLK_REQUIRE(M == 0 || (gating && topk_weights && topk_ids), SGLK_ERR_INVALID, "grouped_topk: null pointer");
+    SGLK_REQUIRE(gating_stride >= E, SGLK_ERR_INVALID, "grouped_topk: gating stride < E");
+    if (M == 0) return SGLK_OK;
+    const dim3 grid((unsigned)ceil_div(M, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define TOPK_LAUNCH(GT, B)                                                                                         \
+    hipLaunchKernelGGL((grouped_topk_kernel<GT, B>), grid, block, 0, s, gating, gating_stride, bias, topk_weights, \
+                       topk_ids, M, E, topk, renormalize, num_expert_group, topk_group)
+    if (bias) {
+        if (gating_type == 0) TOPK_LAUNCH(0, true);
+        else if (gating_type == 1) TOPK_LAUNCH(1, true);
+        else TOPK_LAUNCH(2, true);
+    } else {
+        if (gating_type == 0) TOPK_LAUNCH(0, false);
+        else if (gating_type == 1) TOPK_LAUNCH(1, false);
+        else TOPK_LAUNCH(2, false);
+    }
+#undef TOPK_LAUNCH
+    SGLK_CHECK_LAUNCH("grouped_topk");
+    return SGLK_OK;
+}

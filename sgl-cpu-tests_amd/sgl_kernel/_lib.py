@@ -77,6 +77,17 @@ _SIGNATURES = {
     "sglk_scaled_mm": (ctypes.c_int, [ctypes.POINTER(ScaledMmArgs), ctypes.c_void_p]),
     "sglk_per_token_quant_int8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_silu_and_mul": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_rmsnorm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_fused_add_rmsnorm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                               ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_grouped_topk": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_void_p]),
     "sglk_stage_timer_create": (ctypes.c_void_p, [ctypes.c_int32]),
     "sglk_stage_timer_destroy": (None, [ctypes.c_void_p]),
     "sglk_stage_timer_reset": (None, [ctypes.c_void_p]),

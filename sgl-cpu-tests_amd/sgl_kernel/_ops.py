@@ -372,3 +372,165 @@ _impl("fp8_scaled_mm_cpu", fp8_scaled_mm_cpu)
 _impl("per_token_quant_int8_cpu", per_token_quant_int8_cpu)
 _impl("int8_scaled_mm_cpu", int8_scaled_mm_cpu)
 _impl("int8_scaled_mm_with_quant", int8_scaled_mm_with_quant)
+
+
+# ------------------------------------------------------------------------------------------------------
+# silu_and_mul_cpu: returning form /root/reference/bench_silu_and_mul.py:31; out-param form
+#                   sgl_kernel.ops._kernels.silu_and_mul_cpu(out, x) /root/reference/test_activation.py:25
+# rmsnorm_cpu / fused_add_rmsnorm_cpu: out-param / in-place, /root/reference/test_norm.py:44,56
+# ------------------------------------------------------------------------------------------------------
+_DEF.define("silu_and_mul_cpu(Tensor input) -> Tensor")
+_DEF.define("silu_and_mul_cpu.out(Tensor(a!) out, Tensor input) -> ()")
+_DEF.define("rmsnorm_cpu(Tensor(a!) output, Tensor input, Tensor weight, float eps) -> ()")
+_DEF.define("fused_add_rmsnorm_cpu(Tensor(a!) input, Tensor(b!) residual, Tensor weight, float eps) -> ()")
+
+
+def _is_f16(t, what):
+    if t.dtype == torch.float16:
+        return 1
+    if t.dtype == torch.bfloat16:
+        return 0
+    raise RuntimeError(f"{what}: only bfloat16 / float16 are supported (got {t.dtype})")
+
+
+def _rows2d(t, what):
+    if t.stride(-1) != 1:
+        raise RuntimeError(f"{what}: innermost dimension must be contiguous")
+    if t.dim() == 1:
+        return t.unsqueeze(0)
+    if t.dim() == 2:
+        return t
+    if not t.is_contiguous():
+        raise RuntimeError(f"{what}: tensors with more than 2 dims must be contiguous")
+    return t.view(-1, t.shape[-1])
+
+
+def silu_and_mul_out(out, input):
+    f16 = _is_f16(input, "silu_and_mul")
+    if out.dtype != input.dtype or input.shape[-1] % 2 or out.shape[-1] * 2 != input.shape[-1] \
+            or out.shape[:-1] != input.shape[:-1]:
+        raise RuntimeError("silu_and_mul: expect out [..., d] and input [..., 2d] of the same dtype")
+    x2, o2 = _rows2d(input, "silu_and_mul"), _rows2d(out, "silu_and_mul")
+    rc = _lib.lib().sglk_silu_and_mul(_ptr(x2), x2.stride(0), _ptr(o2), o2.stride(0), x2.shape[0], o2.shape[1], f16,
+                                      _stream(input))
+    _lib.check(rc, "silu_and_mul_cpu")
+
+
+def silu_and_mul_cpu(input):
+    out = torch.empty(input.shape[:-1] + (input.shape[-1] // 2,), dtype=input.dtype, device=input.device)
+    silu_and_mul_out(out, input)
+    return out
+
+
+def rmsnorm_cpu(output, input, weight, eps):
+    f16 = _is_f16(input, "rmsnorm")
+    if output.dtype != input.dtype or weight.dtype != input.dtype or output.shape != input.shape \
+            or weight.shape != input.shape[-1:]:
+        raise RuntimeError("rmsnorm: output/input/weight dtype or shape mismatch")
+    x2, o2 = _rows2d(input, "rmsnorm"), _rows2d(output, "rmsnorm")
+    rc = _lib.lib().sglk_rmsnorm(_ptr(o2), o2.stride(0), _ptr(x2), x2.stride(0), _ptr(weight.contiguous()), x2.shape[0],
+                                 x2.shape[1], float(eps), f16, _stream(input))
+    _lib.check(rc, "rmsnorm_cpu")
+
+
+def fused_add_rmsnorm_cpu(input, residual, weight, eps):
+    f16 = _is_f16(input, "fused_add_rmsnorm")
+    if residual.dtype != input.dtype or weight.dtype != input.dtype or residual.shape != input.shape \
+            or weight.shape != input.shape[-1:]:
+        raise RuntimeError("fused_add_rmsnorm: input/residual/weight dtype or shape mismatch")
+    x2, r2 = _rows2d(input, "fused_add_rmsnorm"), _rows2d(residual, "fused_add_rmsnorm")
+    rc = _lib.lib().sglk_fused_add_rmsnorm(_ptr(x2), x2.stride(0), _ptr(r2), r2.stride(0), _ptr(weight.contiguous()),
+                                           x2.shape[0], x2.shape[1], float(eps), f16, _stream(input))
+    _lib.check(rc, "fused_add_rmsnorm_cpu")
+
+
+_impl("silu_and_mul_cpu", silu_and_mul_cpu)
+_impl("silu_and_mul_cpu.out", silu_and_mul_out, lambda a, args: a is args[0])
+_impl("rmsnorm_cpu", rmsnorm_cpu, lambda a, args: a is args[0])
+_impl("fused_add_rmsnorm_cpu", fused_add_rmsnorm_cpu, lambda a, args: a is args[0] or a is args[1])
+
+# ------------------------------------------------------------------------------------------------------
+# grouped_topk_cpu: returning 9-arg form /root/reference/test_moe.py:61-70; out-param 8-arg form
+#                   /root/reference/test_grouped_topk.py:61-69;  biased_grouped_topk_cpu out-param 9-arg form
+#                   /root/reference/test_biased_grouped_topk.py:71-80
+# ------------------------------------------------------------------------------------------------------
+_DEF.define("grouped_topk_cpu(Tensor hidden_states, Tensor gating_output, int topk, bool renormalize, "
+            "int num_expert_group, int topk_group, int num_fused_shared_experts, float? routed_scaling_factor, "
+            "Tensor? num_token_non_padded) -> (Tensor, Tensor)")
+_DEF.define("grouped_topk_cpu.out(Tensor(a!) topk_weights, Tensor(b!) topk_ids, Tensor hidden_states, "
+            "Tensor gating_output, int topk, bool renormalize, int num_expert_group, int topk_group) -> ()")
+_DEF.define("biased_grouped_topk_cpu(Tensor hidden_states, Tensor gating_output, Tensor correction_bias, int topk, "
+            "bool renormalize, int num_expert_group, int topk_group, int num_fused_shared_experts, "
+            "float? routed_scaling_factor, Tensor? num_token_non_padded) -> (Tensor, Tensor)")
+_DEF.define("biased_grouped_topk_cpu.out(Tensor(a!) topk_weights, Tensor(b!) topk_ids, Tensor hidden_states, "
+            "Tensor gating_output, Tensor correction_bias, int topk, bool renormalize, int num_expert_group, "
+            "int topk_group) -> ()")
+
+_GATE_TYPE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def _grouped_topk(topk_weights, topk_ids, hidden_states, gating, bias, topk, renormalize, G, topk_group):
+    if gating.dim() != 2 or hidden_states.shape[0] != gating.shape[0]:
+        raise RuntimeError("grouped_topk: number of tokens mismatch")
+    if gating.dtype not in _GATE_TYPE:
+        raise RuntimeError(f"grouped_topk: unsupported gating dtype {gating.dtype}")
+    M, E = gating.shape
+    if tuple(topk_weights.shape) != (M, topk) or tuple(topk_ids.shape) != (M, topk) \
+            or topk_weights.dtype != torch.float32 or topk_ids.dtype != torch.int32 \
+            or not topk_weights.is_contiguous() or not topk_ids.is_contiguous():
+        raise RuntimeError("grouped_topk: topk_weights must be contiguous f32 [M,topk], topk_ids contiguous i32 [M,topk]")
+    g = gating if gating.stride(1) == 1 else gating.contiguous()
+    b = None
+    if bias is not None:
+        b = bias.to(gating.dtype).contiguous()
+        if tuple(b.shape) != (E,):
+            raise RuntimeError("biased_grouped_topk: correction_bias must be [E]")
+    rc = _lib.lib().sglk_grouped_topk(_ptr(g), g.stride(0), _GATE_TYPE[g.dtype], _ptr(b), _ptr(topk_weights),
+                                      _ptr(topk_ids), M, E, int(topk), int(bool(renormalize)), int(G), int(topk_group),
+                                      _stream(g))
+    _lib.check(rc, "grouped_topk_cpu")
+
+
+def _check_unsupported(num_fused_shared_experts, routed_scaling_factor, num_token_non_padded):
+    if num_fused_shared_experts or routed_scaling_factor is not None or num_token_non_padded is not None:
+        raise RuntimeError("grouped_topk: num_fused_shared_experts / routed_scaling_factor / num_token_non_padded "
+                           "are not supported (the reference harness only passes 0 / None)")
+
+
+def grouped_topk_cpu(hidden_states, gating_output, topk, renormalize, num_expert_group, topk_group,
+                     num_fused_shared_experts, routed_scaling_factor, num_token_non_padded):
+    _check_unsupported(num_fused_shared_experts, routed_scaling_factor, num_token_non_padded)
+    M = gating_output.shape[0]
+    w = torch.empty(M, topk, dtype=torch.float32, device=gating_output.device)
+    ids = torch.empty(M, topk, dtype=torch.int32, device=gating_output.device)
+    _grouped_topk(w, ids, hidden_states, gating_output, None, topk, renormalize, num_expert_group, topk_group)
+    return w, ids
+
+
+def grouped_topk_out(topk_weights, topk_ids, hidden_states, gating_output, topk, renormalize, num_expert_group,
+                     topk_group):
+    _grouped_topk(topk_weights, topk_ids, hidden_states, gating_output, None, topk, renormalize, num_expert_group,
+                  topk_group)
+
+
+def biased_grouped_topk_cpu(hidden_states, gating_output, correction_bias, topk, renormalize, num_expert_group,
+                            topk_group, num_fused_shared_experts, routed_scaling_factor, num_token_non_padded):
+    _check_unsupported(num_fused_shared_experts, routed_scaling_factor, num_token_non_padded)
+    M = gating_output.shape[0]
+    w = torch.empty(M, topk, dtype=torch.float32, device=gating_output.device)
+    ids = torch.empty(M, topk, dtype=torch.int32, device=gating_output.device)
+    _grouped_topk(w, ids, hidden_states, gating_output, correction_bias, topk, renormalize, num_expert_group, topk_group)
+    return w, ids
+
+
+def biased_grouped_topk_out(topk_weights, topk_ids, hidden_states, gating_output, correction_bias, topk, renormalize,
+                            num_expert_group, topk_group):
+    _grouped_topk(topk_weights, topk_ids, hidden_states, gating_output, correction_bias, topk, renormalize,
+                  num_expert_group, topk_group)
+
+
+_out2 = lambda a, args: a is args[0] or a is args[1]  # noqa: E731
+_impl("grouped_topk_cpu", grouped_topk_cpu)
+_impl("grouped_topk_cpu.out", grouped_topk_out, _out2)
+_impl("biased_grouped_topk_cpu", biased_grouped_topk_cpu)
+_impl("biased_grouped_topk_cpu.out", biased_grouped_topk_out, _out2)

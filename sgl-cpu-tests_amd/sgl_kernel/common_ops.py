@@ -12,3 +12,8 @@ fp8_scaled_mm_cpu = torch.ops.sgl_kernel.fp8_scaled_mm_cpu
 per_token_quant_int8_cpu = torch.ops.sgl_kernel.per_token_quant_int8_cpu
 int8_scaled_mm_cpu = torch.ops.sgl_kernel.int8_scaled_mm_cpu
 int8_scaled_mm_with_quant = torch.ops.sgl_kernel.int8_scaled_mm_with_quant
+silu_and_mul_cpu = torch.ops.sgl_kernel.silu_and_mul_cpu
+rmsnorm_cpu = torch.ops.sgl_kernel.rmsnorm_cpu
+fused_add_rmsnorm_cpu = torch.ops.sgl_kernel.fused_add_rmsnorm_cpu
+grouped_topk_cpu = torch.ops.sgl_kernel.grouped_topk_cpu
+biased_grouped_topk_cpu = torch.ops.sgl_kernel.biased_grouped_topk_cpu

@@ -221,8 +221,25 @@ def gen_shared():
                   input_sha256=checksum(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["fused"])))
 
 
+def gen_rows():
+    from typing import Optional, Tuple, Union
+    ns = lift("test_norm.py", ["forward_native"], {"Optional": Optional, "Tuple": Tuple, "Union": Union})
+    for name, rows, hidden, dtype, seed in recipes.NORM_CASES:
+        inp = recipes.norm_inputs(rows, hidden, dtype, seed)
+        out = ns["forward_native"](inp["x"], inp["w"], 1e-6)
+        out2, res2 = ns["forward_native"](inp["x"], inp["w"], 1e-6, inp["res"])
+        save("norm_" + name, {"ref_out": out, "ref_fused_out": out2, "ref_fused_res": res2},
+             dict(rows=rows, hidden=hidden, dtype=str(dtype), seed=seed, input_sha256=checksum(
+                 *(t.view(torch.int16) for t in (inp["x"], inp["w"], inp["res"])))))
+    nsa = lift("test_activation.py", ["forward_native"])
+    for name, rows, two_d, dtype, seed in recipes.ACT_CASES:
+        inp = recipes.act_inputs(rows, two_d, dtype, seed)
+        save("act_" + name, {"ref_out": nsa["forward_native"](inp["x"])},
+             dict(rows=rows, two_d=two_d, dtype=str(dtype), seed=seed, input_sha256=checksum(inp["x"].view(torch.int16))))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared}
+            "shared": gen_shared, "rows": gen_rows}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(FAMILIES)

@@ -217,3 +217,30 @@ def shared_fp8_inputs(M, N, K, seed, bn=64, bk=128):
                 w1s=torch.randn(2 * N // bn, K // bk, generator=g) * SCALE_FACTOR,
                 w2s=torch.randn(K // bn, N // bk, generator=g) * SCALE_FACTOR,
                 fused=(torch.randn(M, K, generator=g) / math.sqrt(K)).to(torch.bfloat16))
+
+
+# ---- row kernels -----------------------------------------------------------------------------------------------------
+# name, rows, hidden, dtype, seed          (/root/reference/test_norm.py:64-65)
+NORM_CASES = [
+    ("r64_h4096_bf16", 64, 4096, torch.bfloat16, 6111),
+    ("r33_h4109_f16", 33, 4096 + 13, torch.float16, 6112),
+    ("r5_h5120_f16", 5, 5120, torch.float16, 6113),
+]
+# name, rows, two_d, dtype, seed           (/root/reference/test_activation.py:30-31, bench_silu_and_mul.py:60-65)
+ACT_CASES = [
+    ("r16_d22016_bf16", 16, 22016, torch.bfloat16, 6211),
+    ("r17_d22016_f16", 17, 22016, torch.float16, 6212),
+    ("r3_d36864_bf16", 3, 36864, torch.bfloat16, 6213),
+    ("r7_d74_f16", 7, 74, torch.float16, 6214),
+]
+
+
+def norm_inputs(rows, hidden, dtype, seed):
+    g = _gen(seed)
+    return dict(x=torch.randn(rows, hidden, generator=g).to(dtype), w=torch.randn(hidden, generator=g).to(dtype),
+                res=torch.randn(rows, hidden, generator=g).to(dtype))
+
+
+def act_inputs(rows, two_d, dtype, seed):
+    g = _gen(seed)
+    return dict(x=torch.randn(rows, two_d, generator=g).to(dtype))

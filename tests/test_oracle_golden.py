@@ -152,3 +152,80 @@ def test_oracle_shared_expert_fp8(case):
     w2 = moe.dequant_block_fp8(inp["w2"], inp["w2s"], 64, 128)
     out = moe.shared_expert_f32(inp["a"], w1, w2, inp["fused"], rsf)
     torch.testing.assert_close(out, g["ref_out_f32"], rtol=1e-4, atol=1e-5)
+
+
+# ---- routing and row kernels ------------------------------------------------------------------------------------------
+from oracle import elementwise as oew  # noqa: E402
+from oracle import routing  # noqa: E402
+
+
+def routing_keys(g, biased, G, topk_group):
+    """Selection key of every expert (choice inside the selected groups, -inf / -1 outside) and the unbiased scores."""
+    gating = g["gating"].float()
+    M, E = gating.shape
+    if biased:
+        scores = gating.sigmoid()
+        choice = scores + g["bias"].float().unsqueeze(0)
+        gs = torch.sort(choice.view(M, G, -1), dim=-1, descending=True).values[..., :2].sum(-1)
+    else:
+        scores = torch.softmax(gating, dim=-1)
+        choice = scores
+        gs = scores.view(M, G, -1).max(dim=-1).values
+    return scores, choice, gs
+
+
+def check_routing(w, ids, g, biased, G, topk_group, topk, tag=""):
+    """Tie-aware equivalence with the reference oracle's (ref_w, ref_ids): the reference compares scattered [M,E]
+    matrices (/root/reference/test_grouped_topk.py:71-75), which is only well defined without ties at the cut, so:
+    the multiset of selection keys must be identical, the multiset of weights equal, and where the k-th and
+    (k+1)-th keys differ the scattered matrices must agree too."""
+    scores, choice, gs = routing_keys(g, biased, G, topk_group)
+    M, E = scores.shape
+    ref_ids, ref_w = g["ref_ids"].long(), g["ref_w"]
+    ids = ids.long().cpu()
+    w = w.cpu()
+    for m in range(M):
+        assert len(set(ids[m].tolist())) == topk, f"{tag} row {m}: duplicate ids"
+    if biased:   # every pick is pinned by its key; the softmax variant's zero-weight picks are not (masked_fill(0.0))
+        mine_k = torch.sort(choice.gather(1, ids), dim=1).values
+        ref_k = torch.sort(choice.gather(1, ref_ids), dim=1).values
+        assert torch.equal(mine_k, ref_k), f"{tag}: selected keys differ from the reference"
+    res = torch.zeros(M, E).scatter_(1, ids, w)
+    ref = torch.zeros(M, E).scatter_(1, ref_ids, ref_w)
+    row_ok = torch.isclose(res, ref, rtol=1e-5, atol=1e-5).all(dim=1)
+    # rows that disagree must be explained by a tie among the candidates' keys
+    for m in (~row_ok).nonzero().flatten().tolist():
+        a, b = set(ids[m].tolist()), set(ref_ids[m].tolist())
+        ka = sorted(choice[m, list(a - b)].tolist())
+        kb = sorted(choice[m, list(b - a)].tolist())
+        assert ka == kb, f"{tag} row {m}: differs from the reference beyond a tie ({ka} vs {kb})"
+    return int(row_ok.sum())
+
+
+@pytest.mark.parametrize("case", recipes.TOPK_CASES, ids=lambda c: c[0])
+def test_oracle_routing_matches_reference(case):
+    name, M, E, G, topk, topk_group, renorm, biased, seed = case
+    g, _ = load_golden("topk_" + name)
+    if biased:
+        w, ids = routing.biased_grouped_topk(g["gating"], g["bias"], topk, renorm, G, topk_group)
+    else:
+        w, ids = routing.grouped_topk(g["gating"], topk, renorm, G, topk_group)
+    exact_rows = check_routing(w, ids, g, biased, G, topk_group, topk, name)
+    assert exact_rows >= int(0.9 * M)      # ties are the exception
+
+
+@pytest.mark.parametrize("case", recipes.NORM_CASES, ids=lambda c: c[0])
+def test_oracle_rmsnorm(case):
+    name, rows, hidden, dtype, seed = case
+    g, _ = load_golden("norm_" + name)
+    inp = recipes.norm_inputs(rows, hidden, dtype, seed)
+    assert torch.equal(oew.rmsnorm(inp["x"], inp["w"]), g["ref_out"])
+    o, r = oew.rmsnorm(inp["x"], inp["w"], 1e-6, inp["res"])
+    assert torch.equal(o, g["ref_fused_out"]) and torch.equal(r, g["ref_fused_res"])
+
+
+@pytest.mark.parametrize("case", recipes.ACT_CASES, ids=lambda c: c[0])
+def test_oracle_silu_and_mul(case):
+    name, rows, two_d, dtype, seed = case
+    g, _ = load_golden("act_" + name)
+    assert torch.equal(oew.silu_and_mul(recipes.act_inputs(rows, two_d, dtype, seed)["x"]), g["ref_out"])
