@@ -202,6 +202,60 @@ int sglk_grouped_topk(const void* gating, int64_t gating_stride, int32_t gating_
                       int32_t num_expert_group, int32_t topk_group, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * extend_attention            replaces torch.ops.sgl_kernel.extend_attention_cpu
+ *                             (/root/reference/test_extend.py:168-182, bench_extend.py:70-102)
+ * Varlen prefill with a paged prefix: for sequence b the queries are its extend tokens
+ * q[b_start_loc_extend[b] + i], keys/values are k_buffer[req_to_tokens[b_req_idx[b]][0 .. prefix)] (all visible,
+ * prefix = b_seq_len[b] - b_seq_len_extend[b]) followed by the extend tokens k_extend/v_extend (causal).
+ * All tensors bf16 [tokens][heads][dim]; strides {token, head} in elements, innermost dim contiguous.
+ * k_buffer / v_buffer may hold HBUF = 1 head shared by every kv head (the reference's MLA-style case).
+ * Writes o [extend tokens][HQ][DV].  logit_cap > 0 applies cap * tanh(logit / cap).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void *q, *k_extend, *v_extend, *k_buffer, *v_buffer;
+    void* o;
+    int64_t q_stride[2], k_extend_stride[2], v_extend_stride[2], k_buffer_stride[2], v_buffer_stride[2], o_stride[2];
+    const void* req_to_tokens;       /* [B][L] int32 or int64 */
+    int64_t req_to_tokens_stride;
+    int32_t req_to_tokens_is64;
+    const int64_t* b_req_idx;        /* [B] */
+    const int64_t* b_seq_len;        /* [B] */
+    const int32_t* b_seq_len_extend; /* [B] */
+    const int32_t* b_start_loc_extend; /* [B] */
+    int32_t B, HQ, HKV, HBUF, D, DV, max_len_extend;
+    float sm_scale, logit_cap;
+} sglk_extend_attention_args;
+
+int sglk_extend_attention(const sglk_extend_attention_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * decode_attention            replaces torch.ops.sgl_kernel.decode_attention_cpu
+ *                             (/root/reference/test_mla.py:115-128, test_decoding.py:107-120)
+ * 1. k_buffer[loc[b]] = key[b]; v_buffer[loc[b]] = value[b] (bit-exact), 2. one-token attention of q[b] over
+ * req_to_token[b_req_idx[b]][0 .. b_seq_len[b]) in `splits` key ranges whose partial results (O/l, log-sum-exp)
+ * go to the caller's scratch attn_logits [B][HQ][splits][DV+1] f32, 3. merge into o [B][HQ][DV] bf16.
+ * v_buffer may be a view of k_buffer (MLA: v = k[..., :DV]); then K is read once and serves as V.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* q;
+    void *k_buffer, *v_buffer, *o;
+    const void *key, *value;
+    int64_t q_stride[2], k_buffer_stride[2], v_buffer_stride[2], o_stride[2], key_stride[2], value_stride[2];
+    const void* loc;                 /* [B] int32 or int64 */
+    int32_t loc_is64;
+    float* attn_logits;
+    const void* req_to_token;        /* [B][L] int32 or int64 */
+    int64_t req_to_token_stride;
+    int32_t req_to_token_is64;
+    const int64_t* b_req_idx;
+    const int64_t* b_seq_len;
+    int32_t B, HQ, HKV, D, DV, splits;
+    float sm_scale, logit_cap;
+} sglk_decode_attention_args;
+
+int sglk_decode_attention(const sglk_decode_attention_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Stages of fused_experts exposed for tests and profiling (same kernels the fused call launches).
  * moe_align: counting sort of the M*topk slots by expert (ids outside [0,E) dropped), stable in slot order.
  *   sorted_slot [M*topk] i32   slot = m*topk + j, grouped by expert

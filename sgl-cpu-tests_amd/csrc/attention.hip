@@ -1,0 +1,506 @@
+// extend_attention / decode_attention: paged-KV flash attention on bf16 MFMA.
+//
+// Replaces torch.ops.sgl_kernel.extend_attention_cpu (/root/reference/test_extend.py:168-182, bench_extend.py:70-102)
+// and decode_attention_cpu (/root/reference/test_mla.py:115-128, test_decoding.py:107-120).  Oracles:
+// _run_sdpa_forward_extend (/root/reference/test_extend.py:10-76) and _run_sdpa_forward_decode (test_mla.py:12-66).
+//
+// One device core serves both.  A wave owns QT tiles of 16 "query columns" that share one K/V stream:
+//   extend : columns = consecutive query positions of one (sequence, q head);  keys = paged prefix (all visible) then
+//            the extend tokens (causal)
+//   decode : columns = the q heads of one kv head (GQA / MLA group), one position;  keys = one split of the sequence
+// Per 64-key tile (K and V staged in LDS once per workgroup):
+//   S^T = K . Q^T   keys are the MFMA rows, queries the columns -> a lane owns ONE query column: its running max / sum
+//                    are plain per-lane scalars and the only cross-lane traffic is two shuffles per tile for the max;
+//   P = exp(S - m)  stays in the accumulator registers and IS the B operand of the next product (16 keys of tile 2s
+//                    and 16 of tile 2s+1 form the 32-deep k-step; the matching A operand rows of V come from
+//                    ds_read_b64_tr_b16, which transposes 4 keys x 16 columns out of the row-major V image);
+//   O^T += V^T . P
+// K rows are 16-byte-chunk XOR-swizzled in LDS (conflict-free ds_read_b128); when V aliases K (MLA: v_buffer is
+// k_buffer[..., :DV], /root/reference/test_mla.py:83) the K image is reused for V and K is read from HBM once.
+// fp32 softmax, bf16 P, fp32 accumulation; optional logit soft-cap.  Decode writes per-split (O/l, lse) into the
+// caller's attn_logits [B][HQ][splits][DV+1] and a merge kernel combines them.
+#include "sglk_common.h"
+
+namespace sglk {
+namespace attn {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int kKeys = 64;   // keys per tile
+
+template <int CHUNKS>
+struct Swz {   // XOR mask for 16-byte chunks of a row with CHUNKS chunks (mask+1 must divide CHUNKS)
+    static constexpr int mask = (CHUNKS % 8 == 0) ? 7 : ((CHUNKS % 4 == 0) ? 3 : ((CHUNKS % 2 == 0) ? 1 : 0));
+};
+
+struct KvSource {
+    // key position p of the stream -> row pointer.  p < n_paged: buf + page[p] * stride_tok;  else ext + (p - n_paged) * ext_stride_tok
+    const unsigned short* buf;
+    int64_t buf_stride_tok;
+    const void* page;     // int32 or int64 token ids
+    int page_is64;
+    int n_paged;
+    const unsigned short* ext;
+    int64_t ext_stride_tok;
+};
+
+SGLK_DEV const unsigned short* kv_row(const KvSource& s, int p) {
+    if (p < s.n_paged) {
+        const int64_t tok = s.page_is64 ? reinterpret_cast<const int64_t*>(s.page)[p] : (int64_t)reinterpret_cast<const int*>(s.page)[p];
+        return s.buf + tok * s.buf_stride_tok;
+    }
+    return s.ext + (int64_t)(p - s.n_paged) * s.ext_stride_tok;
+}
+
+// stage `nkeys` (<= 64) rows of WIDTH bf16 into the swizzled LDS image; missing rows are zero-filled
+template <int WIDTH, int THREADS>
+SGLK_DEV void stage_tile(unsigned char* lds, const KvSource& src, int p0, int nkeys, const unsigned short** rowptr_lds) {
+    constexpr int CH = WIDTH / 8;
+    constexpr int MASK = Swz<CH>::mask;
+    if (threadIdx.x < kKeys) rowptr_lds[threadIdx.x] = threadIdx.x < nkeys ? kv_row(src, p0 + threadIdx.x) : nullptr;
+    __syncthreads();
+    for (int c = threadIdx.x; c < kKeys * CH; c += THREADS) {
+        const int row = c / CH, ch = c - row * CH;
+        const unsigned short* rp = rowptr_lds[row];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (rp) v = *reinterpret_cast<const uint4*>(rp + ch * 8);
+        *reinterpret_cast<uint4*>(lds + row * (WIDTH * 2) + ((ch ^ (row & MASK)) << 4)) = v;
+    }
+}
+
+// Per-wave attention state and the per-tile update.  D, DV: head dims of K and V; QT: 16-column query tiles.
+template <int D, int DV, int QT>
+struct Core {
+    static constexpr int KS = D / 32;       // k-steps of Q.K
+    static constexpr int VT = DV / 16;      // output tiles
+    static constexpr int KCH = D / 8, VCH = DV / 8;
+
+    bf16x8 qf[QT][KS];
+    f32x4 o[QT][VT];
+    float m[QT], l[QT];
+
+    SGLK_DEV void init() {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            m[qt] = -INFINITY;
+            l[qt] = 0.f;
+#pragma unroll
+            for (int t = 0; t < VT; ++t) o[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // column qt*16 + (lane&15) reads its query row (nullptr = padding column)
+    SGLK_DEV void load_q(int qt, const unsigned short* qrow, int lane) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qrow) v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + g * 8);
+            qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    // one 64-key tile.  key_base: stream position of the tile's first key; limit[qt]: the lane's column may see keys
+    // with position < limit; V_ALIAS: V rows live in the K image (row width D), else in its own image (row width DV)
+    template <bool V_ALIAS>
+    SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
+                       float scale_log2e, float logit_cap, int lane) {
+        constexpr int KMASK = Swz<KCH>::mask;
+        constexpr int VW = V_ALIAS ? D : DV;                 // row width of the image V is read from
+        constexpr int VMASK = V_ALIAS ? KMASK : Swz<VCH>::mask;
+        const int r = lane & 15, g = lane >> 4;
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // ---- S^T = K . Q^T ----
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int row = kt * 16 + r;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(klds + row * (D * 2) + (((ks * 4 + g) ^ (row & KMASK)) << 4));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax per column (lane) ----
+        bf16x8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = s[qt][kt][j] * scale_log2e;          // logits in log2 units
+                    if (logit_cap > 0.f) {
+                        // cap * tanh(x / cap) on the natural-log-scale logit
+                        const float x = v * 0.6931471805599453f;
+                        v = logit_cap * tanhf(x / logit_cap) * 1.4426950408889634f;
+                    }
+                    const int key = key_base + kt * 16 + g * 4 + j;
+                    v = key < limit[qt] ? v : -INFINITY;
+                    s[qt][kt][j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m[qt], mx);
+            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qt] - m_new);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            float psum = 0.f;
+            float p[4][4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    p[kt][j] = __builtin_amdgcn_exp2f(s[qt][kt][j] - m_use);   // exp2(-inf) = 0 for masked keys
+                    psum += p[kt][j];
+                }
+            m[qt] = m_new;
+            l[qt] = l[qt] * alpha + psum;     // per-lane partial (this lane's keys); lane groups are summed at the end
+#pragma unroll
+            for (int t = 0; t < VT; ++t) o[qt][t] *= alpha;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                u32x4 w;
+                w[0] = pack_bf16x2(p[2 * ss][0], p[2 * ss][1]);
+                w[1] = pack_bf16x2(p[2 * ss][2], p[2 * ss][3]);
+                w[2] = pack_bf16x2(p[2 * ss + 1][0], p[2 * ss + 1][1]);
+                w[3] = pack_bf16x2(p[2 * ss + 1][2], p[2 * ss + 1][3]);
+                pf[qt][ss] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        // ---- O^T += V^T . P ----
+        const int q = r >> 2, pp = r & 3;   // transposed read: lane supplies row q, columns 4pp.. of its group's 4x16 block
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const int row0 = ss * 32 + g * 4 + q;
+                const int row1 = row0 + 16;
+                const int col = t * 16 + pp * 4;            // in elements; 4 elements = 8 bytes inside one 16-B chunk
+                const int ch = col >> 3, sub = (col & 7) * 2;
+                const unsigned char* a0 = vlds + row0 * (VW * 2) + ((ch ^ (row0 & VMASK)) << 4) + sub;
+                const unsigned char* a1 = vlds + row1 * (VW * 2) + ((ch ^ (row1 & VMASK)) << 4) + sub;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                s16x8 vv;
+                vv[0] = lo[0]; vv[1] = lo[1]; vv[2] = lo[2]; vv[3] = lo[3];
+                vv[4] = hi[0]; vv[5] = hi[1]; vv[6] = hi[2]; vv[7] = hi[3];
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ss], o[qt][t], 0, 0, 0);
+            }
+        }
+    }
+
+    // total of the per-lane partial sums of a column (the 4 lane groups hold disjoint keys)
+    SGLK_DEV float column_sum(int qt) const {
+        float v = l[qt];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// extend attention
+// ---------------------------------------------------------------------------------------------------------------------
+struct ExtendParams {
+    const unsigned short *q, *k_ext, *v_ext, *k_buf, *v_buf;
+    unsigned short* o;
+    int64_t q_s0, q_s1, ke_s0, ke_s1, ve_s0, ve_s1, kb_s0, kb_s1, vb_s0, vb_s1, o_s0, o_s1;   // element strides [token][head]
+    const void* req_to_tokens;   // [B][L]
+    int64_t rtt_stride;
+    int rtt_is64;
+    const int64_t* b_req_idx;
+    const int64_t* b_seq_len;
+    const int* b_seq_len_extend;
+    const int* b_start_loc_extend;
+    int HQ, HKV, HBUF;
+    float sm_scale, logit_cap;
+};
+
+template <int D, int DV>
+__global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParams p) {
+    constexpr int QB = 128;   // queries per workgroup: 4 waves x 2 tiles x 16
+    __shared__ __attribute__((aligned(16))) unsigned char klds[kKeys * D * 2];
+    __shared__ __attribute__((aligned(16))) unsigned char vlds[kKeys * DV * 2];
+    __shared__ const unsigned short* rowptr[2][kKeys];
+
+    const int b = blockIdx.y, h = blockIdx.z;
+    const int ext_len = p.b_seq_len_extend[b];
+    const int q0 = blockIdx.x * QB;
+    if (q0 >= ext_len) return;
+    const int seq_len = (int)p.b_seq_len[b];
+    const int prefix = seq_len - ext_len;
+    const int ext_start = p.b_start_loc_extend[b];
+    const int64_t req = p.b_req_idx[b];
+    const int kvh = h / (p.HQ / p.HKV);
+    const int kvh_buf = p.HBUF == p.HKV ? kvh : 0;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Core<D, DV, 2> core;
+    core.init();
+    int limit[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = q0 + wave * 32 + qt * 16 + (lane & 15);
+        const bool valid = qi < ext_len;
+        core.load_q(qt, valid ? p.q + (int64_t)(ext_start + qi) * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
+        limit[qt] = valid ? prefix + qi + 1 : 0;     // causal: keys up to and including the query's own position
+    }
+    KvSource ks, vs;
+    const unsigned char* page = reinterpret_cast<const unsigned char*>(p.req_to_tokens) + req * p.rtt_stride * (p.rtt_is64 ? 8 : 4);
+    ks.buf = p.k_buf + (int64_t)kvh_buf * p.kb_s1; ks.buf_stride_tok = p.kb_s0; ks.page = page; ks.page_is64 = p.rtt_is64; ks.n_paged = prefix;
+    ks.ext = p.k_ext + (int64_t)ext_start * p.ke_s0 + (int64_t)kvh * p.ke_s1; ks.ext_stride_tok = p.ke_s0;
+    vs = ks;
+    vs.buf = p.v_buf + (int64_t)kvh_buf * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
+    vs.ext = p.v_ext + (int64_t)ext_start * p.ve_s0 + (int64_t)kvh * p.ve_s1; vs.ext_stride_tok = p.ve_s0;
+
+    const int q_last = (q0 + QB < ext_len ? q0 + QB : ext_len);
+    const int kv_end = prefix + q_last;       // the block's last query sees keys < prefix + q_last
+    const float scale_log2e = p.sm_scale * 1.4426950408889634f;
+    for (int p0 = 0; p0 < kv_end; p0 += kKeys) {
+        const int nk = kv_end - p0 < kKeys ? kv_end - p0 : kKeys;
+        __syncthreads();   // previous tile fully consumed
+        stage_tile<D, 256>(klds, ks, p0, nk, rowptr[0]);
+        stage_tile<DV, 256>(vlds, vs, p0, nk, rowptr[1]);
+        __syncthreads();
+        core.template tile<false>(klds, vlds, p0, limit, scale_log2e, p.logit_cap, lane);
+    }
+    // ---- normalise and store: lane (g, column) holds output dims 16t + 4g .. +3 of its query ----
+    const int g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float lsum = core.column_sum(qt);
+        const int qi = q0 + wave * 32 + qt * 16 + (lane & 15);
+        if (qi >= ext_len) continue;
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        unsigned short* orow = p.o + (int64_t)(ext_start + qi) * p.o_s0 + (int64_t)h * p.o_s1;
+#pragma unroll
+        for (int t = 0; t < DV / 16; ++t) {
+            const f32x4 v = core.o[qt][t] * inv;
+            uint2 w;
+            w.x = pack_bf16x2(v[0], v[1]);
+            w.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(orow + t * 16 + g4) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// decode attention: cache write, split-KV partials, merge
+// ---------------------------------------------------------------------------------------------------------------------
+// k_buffer[loc[b]] = key[b]; v_buffer[loc[b]] = value[b]  (bit-exact copies; /root/reference/test_mla.py:27,174-175)
+__global__ __launch_bounds__(256) void kv_cache_write_kernel(unsigned short* k_buf, int64_t kb_s0, int64_t kb_s1,
+                                                             unsigned short* v_buf, int64_t vb_s0, int64_t vb_s1,
+                                                             const unsigned short* key, int64_t k_s0, int64_t k_s1,
+                                                             const unsigned short* value, int64_t v_s0, int64_t v_s1,
+                                                             const void* loc, int loc_is64, int B, int HKV, int D, int DV) {
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int64_t tok = loc_is64 ? reinterpret_cast<const int64_t*>(loc)[b] : (int64_t)reinterpret_cast<const int*>(loc)[b];
+    for (int c = threadIdx.x; c < D; c += 256) k_buf[tok * kb_s0 + h * kb_s1 + c] = key[(int64_t)b * k_s0 + h * k_s1 + c];
+    for (int c = threadIdx.x; c < DV; c += 256) v_buf[tok * vb_s0 + h * vb_s1 + c] = value[(int64_t)b * v_s0 + h * v_s1 + c];
+}
+
+struct DecodeParams {
+    const unsigned short *q, *k_buf, *v_buf;
+    int64_t q_s0, q_s1, kb_s0, kb_s1, vb_s0, vb_s1;
+    float* logits;          // [B][HQ][splits][DV+1]
+    const void* req_to_token;
+    int64_t rtt_stride;
+    int rtt_is64;
+    const int64_t* b_req_idx;
+    const int64_t* b_seq_len;
+    int HQ, HKV, splits, v_alias;
+    float sm_scale, logit_cap;
+};
+
+template <int D, int DV, bool V_ALIAS>
+__global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodeParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+    unsigned char* klds = dyn_lds;
+    unsigned char* vlds = V_ALIAS ? dyn_lds : dyn_lds + kKeys * D * 2;
+    const unsigned short** rowptr = reinterpret_cast<const unsigned short**>(dyn_lds + kKeys * D * 2 + (V_ALIAS ? 0 : kKeys * DV * 2));
+
+    const int b = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+    const int group = p.HQ / p.HKV;
+    const int seq_len = (int)p.b_seq_len[b];
+    const int per = (seq_len + p.splits - 1) / p.splits;
+    const int k_begin = split * per;
+    const int k_end = (k_begin + per < seq_len) ? k_begin + per : seq_len;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = wave * 16 + (lane & 15);            // q head inside the group handled by this lane's column
+    const bool col_valid = col < group;
+    const bool wave_active = wave * 16 < group;
+    const int h = kvh * group + col;
+
+    Core<D, DV, 1> core;
+    core.init();
+    if (wave_active) core.load_q(0, col_valid ? p.q + (int64_t)b * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
+    int limit[1] = {col_valid ? k_end : 0};
+
+    const int64_t req = p.b_req_idx[b];
+    KvSource ks, vs;
+    const unsigned char* page = reinterpret_cast<const unsigned char*>(p.req_to_token) + req * p.rtt_stride * (p.rtt_is64 ? 8 : 4);
+    ks.buf = p.k_buf + (int64_t)kvh * p.kb_s1; ks.buf_stride_tok = p.kb_s0; ks.page = page; ks.page_is64 = p.rtt_is64;
+    ks.n_paged = seq_len; ks.ext = nullptr; ks.ext_stride_tok = 0;
+    vs = ks;
+    vs.buf = p.v_buf + (int64_t)kvh * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
+    const float scale_log2e = p.sm_scale * 1.4426950408889634f;
+    for (int p0 = k_begin; p0 < k_end; p0 += kKeys) {
+        const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
+        __syncthreads();
+        // positions are absolute stream positions: stage_tile adds threadIdx to p0
+        stage_tile<D, 256>(klds, ks, p0, nk, rowptr);
+        if (!V_ALIAS) {
+            __syncthreads();   // rowptr is reused
+            stage_tile<DV, 256>(vlds, vs, p0, nk, rowptr);
+        }
+        __syncthreads();
+        if (wave_active) core.template tile<V_ALIAS>(klds, vlds, p0, limit, scale_log2e, p.logit_cap, lane);
+    }
+    if (!wave_active) return;
+    const float lsum = core.column_sum(0);
+    if (!col_valid) return;
+    float* dst = p.logits + (((int64_t)b * p.HQ + h) * p.splits + split) * (DV + 1);
+    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+    const int g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int t = 0; t < DV / 16; ++t) {
+        const f32x4 v = core.o[0][t] * inv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[t * 16 + g4 + j] = v[j];
+    }
+    // log-sum-exp of the split in log2 units (m is in log2 units); -inf marks an empty split
+    if ((lane >> 4) == 0) dst[DV] = lsum > 0.f ? core.m[0] + __builtin_amdgcn_logf(lsum) : -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ logits, unsigned short* __restrict__ o,
+                                                           int64_t o_s0, int64_t o_s1, int HQ, int splits, int DV) {
+    const int b = blockIdx.x, h = blockIdx.y;
+    const float* src = logits + ((int64_t)b * HQ + h) * splits * (DV + 1);
+    float mx = -INFINITY;
+    for (int s = 0; s < splits; ++s) mx = fmaxf(mx, src[s * (DV + 1) + DV]);
+    float wsum = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float lse = src[s * (DV + 1) + DV];
+        wsum += (lse == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(lse - mx);
+    }
+    for (int c = threadIdx.x; c < DV; c += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < splits; ++s) {
+            const float lse = src[s * (DV + 1) + DV];
+            if (lse == -INFINITY) continue;
+            acc += __builtin_amdgcn_exp2f(lse - mx) * src[s * (DV + 1) + c];
+        }
+        o[(int64_t)b * o_s0 + (int64_t)h * o_s1 + c] = f32_to_bf16_bits(wsum > 0.f ? acc / wsum : 0.f);
+    }
+}
+
+}  // namespace attn
+}  // namespace sglk
+
+using namespace sglk;
+using namespace sglk::attn;
+
+extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "extend_attention: null args");
+    SGLK_REQUIRE(a->B >= 0 && a->HQ > 0 && a->HKV > 0 && a->HQ % a->HKV == 0, SGLK_ERR_INVALID,
+                 "extend_attention: bad head counts HQ=%d HKV=%d", a->HQ, a->HKV);
+    SGLK_REQUIRE(a->HBUF == a->HKV || a->HBUF == 1, SGLK_ERR_SHAPE, "extend_attention: buffer heads (%d) must equal HKV (%d) or 1", a->HBUF, a->HKV);
+    if (a->B == 0 || a->max_len_extend <= 0) return SGLK_OK;
+    SGLK_REQUIRE(a->q && a->k_extend && a->v_extend && a->o && a->k_buffer && a->v_buffer && a->req_to_tokens && a->b_req_idx &&
+                     a->b_seq_len && a->b_seq_len_extend && a->b_start_loc_extend,
+                 SGLK_ERR_INVALID, "extend_attention: null pointer");
+    ExtendParams p{};
+    p.q = (const unsigned short*)a->q; p.k_ext = (const unsigned short*)a->k_extend; p.v_ext = (const unsigned short*)a->v_extend;
+    p.k_buf = (const unsigned short*)a->k_buffer; p.v_buf = (const unsigned short*)a->v_buffer; p.o = (unsigned short*)a->o;
+    p.q_s0 = a->q_stride[0]; p.q_s1 = a->q_stride[1]; p.ke_s0 = a->k_extend_stride[0]; p.ke_s1 = a->k_extend_stride[1];
+    p.ve_s0 = a->v_extend_stride[0]; p.ve_s1 = a->v_extend_stride[1]; p.kb_s0 = a->k_buffer_stride[0]; p.kb_s1 = a->k_buffer_stride[1];
+    p.vb_s0 = a->v_buffer_stride[0]; p.vb_s1 = a->v_buffer_stride[1]; p.o_s0 = a->o_stride[0]; p.o_s1 = a->o_stride[1];
+    p.req_to_tokens = a->req_to_tokens; p.rtt_stride = a->req_to_tokens_stride; p.rtt_is64 = a->req_to_tokens_is64;
+    p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.b_seq_len_extend = a->b_seq_len_extend;
+    p.b_start_loc_extend = a->b_start_loc_extend; p.HQ = a->HQ; p.HKV = a->HKV; p.HBUF = a->HBUF;
+    p.sm_scale = a->sm_scale; p.logit_cap = a->logit_cap;
+    // 16-byte row accesses
+    const int64_t strides[] = {p.q_s0, p.q_s1, p.ke_s0, p.ke_s1, p.ve_s0, p.ve_s1, p.kb_s0, p.kb_s1, p.vb_s0, p.vb_s1};
+    for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "extend_attention: q/k/v strides must be multiples of 8 elements");
+    SGLK_REQUIRE(p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0, SGLK_ERR_SHAPE, "extend_attention: o strides must be multiples of 4 elements");
+    const dim3 grid((unsigned)ceil_div(a->max_len_extend, 128), (unsigned)a->B, (unsigned)a->HQ), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define EXT_CASE(DD, DDV)                                                                              \
+    if (a->D == DD && a->DV == DDV) {                                                                  \
+        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV>), grid, block, 0, s, p);                  \
+        SGLK_CHECK_LAUNCH("extend_attention");                                                         \
+        return SGLK_OK;                                                                                \
+    }
+    EXT_CASE(128, 128)
+    EXT_CASE(128, 96)
+    EXT_CASE(192, 128)
+    EXT_CASE(64, 64)
+#undef EXT_CASE
+    SGLK_FAIL(SGLK_ERR_SHAPE, "extend_attention: head dims D=%d DV=%d not built (have 128/128, 128/96, 192/128, 64/64)", a->D, a->DV);
+}
+
+extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "decode_attention: null args");
+    SGLK_REQUIRE(a->B >= 0 && a->HQ > 0 && a->HKV > 0 && a->HQ % a->HKV == 0, SGLK_ERR_INVALID,
+                 "decode_attention: bad head counts HQ=%d HKV=%d", a->HQ, a->HKV);
+    SGLK_REQUIRE(a->HQ / a->HKV <= 64, SGLK_ERR_SHAPE, "decode_attention: at most 64 q heads per kv head");
+    SGLK_REQUIRE(a->splits > 0, SGLK_ERR_INVALID, "decode_attention: attn_logits must have >= 1 split");
+    if (a->B == 0) return SGLK_OK;
+    SGLK_REQUIRE(a->q && a->k_buffer && a->v_buffer && a->o && a->key && a->value && a->loc && a->attn_logits && a->req_to_token &&
+                     a->b_req_idx && a->b_seq_len, SGLK_ERR_INVALID, "decode_attention: null pointer");
+    const int64_t strides[] = {a->q_stride[0], a->q_stride[1], a->k_buffer_stride[0], a->k_buffer_stride[1],
+                               a->v_buffer_stride[0], a->v_buffer_stride[1]};
+    for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "decode_attention: q/k/v strides must be multiples of 8 elements");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(kv_cache_write_kernel, dim3((unsigned)a->B, (unsigned)a->HKV), dim3(256), 0, s,
+                       (unsigned short*)a->k_buffer, a->k_buffer_stride[0], a->k_buffer_stride[1], (unsigned short*)a->v_buffer,
+                       a->v_buffer_stride[0], a->v_buffer_stride[1], (const unsigned short*)a->key, a->key_stride[0],
+                       a->key_stride[1], (const unsigned short*)a->value, a->value_stride[0], a->value_stride[1], a->loc,
+                       a->loc_is64, a->B, a->HKV, a->D, a->DV);
+    SGLK_CHECK_LAUNCH("decode_attention(cache write)");
+    DecodeParams p{};
+    p.q = (const unsigned short*)a->q; p.k_buf = (const unsigned short*)a->k_buffer; p.v_buf = (const unsigned short*)a->v_buffer;
+    p.q_s0 = a->q_stride[0]; p.q_s1 = a->q_stride[1]; p.kb_s0 = a->k_buffer_stride[0]; p.kb_s1 = a->k_buffer_stride[1];
+    p.vb_s0 = a->v_buffer_stride[0]; p.vb_s1 = a->v_buffer_stride[1]; p.logits = a->attn_logits;
+    p.req_to_token = a->req_to_token; p.rtt_stride = a->req_to_token_stride; p.rtt_is64 = a->req_to_token_is64;
+    p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.HQ = a->HQ; p.HKV = a->HKV; p.splits = a->splits;
+    p.sm_scale = a->sm_scale; p.logit_cap = a->logit_cap;
+    // V aliases K when it is the same storage with the same strides (MLA: v = k[..., :DV])
+    const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
+                       a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
+    const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)a->splits), block(256);
+#define DEC_CASE(DD, DDV)                                                                                          \
+    if (a->D == DD && a->DV == DDV) {                                                                              \
+        if (alias) {                                                                                               \
+            const size_t lds = (size_t)kKeys * DD * 2 + kKeys * 8;                                                 \
+            hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, true>), grid, block, lds, s, p);                  \
+        } else {                                                                                                   \
+            const size_t lds = (size_t)kKeys * (DD + DDV) * 2 + kKeys * 8;                                         \
+            hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, false>), grid, block, lds, s, p);                 \
+        }                                                                                                          \
+        SGLK_CHECK_LAUNCH("decode_attention");                                                                     \
+        hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)a->B, (unsigned)a->HQ), dim3(256), 0, s, a->attn_logits,    \
+                           (unsigned short*)a->o, a->o_stride[0], a->o_stride[1], a->HQ, a->splits, a->DV);        \
+        SGLK_CHECK_LAUNCH("decode_attention(merge)");                                                              \
+        return SGLK_OK;                                                                                            \
+    }
+    DEC_CASE(576, 512)
+    DEC_CASE(128, 128)
+    DEC_CASE(192, 128)
+    DEC_CASE(64, 64)
+#undef DEC_CASE
+    SGLK_FAIL(SGLK_ERR_SHAPE, "decode_attention: head dims D=%d DV=%d not built (have 576/512, 128/128, 192/128, 64/64)", a->D, a->DV);
+}

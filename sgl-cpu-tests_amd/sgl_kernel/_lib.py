@@ -52,6 +52,37 @@ class ScaledMmArgs(ctypes.Structure):
     ]
 
 
+class ExtendAttentionArgs(ctypes.Structure):
+    """Mirror of `sglk_extend_attention_args`."""
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("k_extend", ctypes.c_void_p), ("v_extend", ctypes.c_void_p),
+        ("k_buffer", ctypes.c_void_p), ("v_buffer", ctypes.c_void_p), ("o", ctypes.c_void_p),
+        ("q_stride", ctypes.c_int64 * 2), ("k_extend_stride", ctypes.c_int64 * 2), ("v_extend_stride", ctypes.c_int64 * 2),
+        ("k_buffer_stride", ctypes.c_int64 * 2), ("v_buffer_stride", ctypes.c_int64 * 2), ("o_stride", ctypes.c_int64 * 2),
+        ("req_to_tokens", ctypes.c_void_p), ("req_to_tokens_stride", ctypes.c_int64), ("req_to_tokens_is64", ctypes.c_int32),
+        ("b_req_idx", ctypes.c_void_p), ("b_seq_len", ctypes.c_void_p), ("b_seq_len_extend", ctypes.c_void_p),
+        ("b_start_loc_extend", ctypes.c_void_p),
+        ("B", ctypes.c_int32), ("HQ", ctypes.c_int32), ("HKV", ctypes.c_int32), ("HBUF", ctypes.c_int32),
+        ("D", ctypes.c_int32), ("DV", ctypes.c_int32), ("max_len_extend", ctypes.c_int32),
+        ("sm_scale", ctypes.c_float), ("logit_cap", ctypes.c_float),
+    ]
+
+
+class DecodeAttentionArgs(ctypes.Structure):
+    """Mirror of `sglk_decode_attention_args`."""
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("k_buffer", ctypes.c_void_p), ("v_buffer", ctypes.c_void_p), ("o", ctypes.c_void_p),
+        ("key", ctypes.c_void_p), ("value", ctypes.c_void_p),
+        ("q_stride", ctypes.c_int64 * 2), ("k_buffer_stride", ctypes.c_int64 * 2), ("v_buffer_stride", ctypes.c_int64 * 2),
+        ("o_stride", ctypes.c_int64 * 2), ("key_stride", ctypes.c_int64 * 2), ("value_stride", ctypes.c_int64 * 2),
+        ("loc", ctypes.c_void_p), ("loc_is64", ctypes.c_int32), ("attn_logits", ctypes.c_void_p),
+        ("req_to_token", ctypes.c_void_p), ("req_to_token_stride", ctypes.c_int64), ("req_to_token_is64", ctypes.c_int32),
+        ("b_req_idx", ctypes.c_void_p), ("b_seq_len", ctypes.c_void_p),
+        ("B", ctypes.c_int32), ("HQ", ctypes.c_int32), ("HKV", ctypes.c_int32), ("D", ctypes.c_int32),
+        ("DV", ctypes.c_int32), ("splits", ctypes.c_int32), ("sm_scale", ctypes.c_float), ("logit_cap", ctypes.c_float),
+    ]
+
+
 OUT_BF16, OUT_F16, OUT_F32 = 0, 1, 2
 
 # symbol -> (restype, argtypes); every symbol include/sglk.h declares must be listed here
@@ -88,6 +119,8 @@ _SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_void_p]),
+    "sglk_extend_attention": (ctypes.c_int, [ctypes.POINTER(ExtendAttentionArgs), ctypes.c_void_p]),
+    "sglk_decode_attention": (ctypes.c_int, [ctypes.POINTER(DecodeAttentionArgs), ctypes.c_void_p]),
     "sglk_stage_timer_create": (ctypes.c_void_p, [ctypes.c_int32]),
     "sglk_stage_timer_destroy": (None, [ctypes.c_void_p]),
     "sglk_stage_timer_reset": (None, [ctypes.c_void_p]),

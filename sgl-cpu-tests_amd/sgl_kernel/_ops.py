@@ -534,3 +534,91 @@ _impl("grouped_topk_cpu", grouped_topk_cpu)
 _impl("grouped_topk_cpu.out", grouped_topk_out, _out2)
 _impl("biased_grouped_topk_cpu", biased_grouped_topk_cpu)
 _impl("biased_grouped_topk_cpu.out", biased_grouped_topk_out, _out2)
+
+
+# ------------------------------------------------------------------------------------------------------
+# extend_attention_cpu (/root/reference/test_extend.py:168-182), decode_attention_cpu (/root/reference/test_mla.py:115-128)
+# both write into caller-allocated outputs and return None
+# ------------------------------------------------------------------------------------------------------
+_DEF.define("extend_attention_cpu(Tensor q_extend, Tensor k_extend, Tensor v_extend, Tensor(a!) o_extend, "
+            "Tensor k_buffer, Tensor v_buffer, Tensor req_to_tokens, Tensor b_req_idx, Tensor b_seq_len, "
+            "Tensor b_seq_len_extend, Tensor b_start_loc_extend, int max_len_extend, float sm_scale, "
+            "float logit_cap) -> ()")
+_DEF.define("decode_attention_cpu(Tensor query, Tensor(a!) k_buffer, Tensor(b!) v_buffer, Tensor(c!) output, "
+            "Tensor key, Tensor value, Tensor loc, Tensor(d!) attn_logits, Tensor req_to_token, Tensor b_req_idx, "
+            "Tensor b_seq_len, float sm_scale, float logit_cap) -> ()")
+
+
+def _thd(t, what):
+    if t.dim() != 3 or t.dtype != torch.bfloat16 or t.stride(2) != 1:
+        raise RuntimeError(f"{what}: expect a bfloat16 [tokens, heads, dim] tensor with a contiguous last dim")
+    return t
+
+
+def _s2(t):
+    return (ctypes.c_int64 * 2)(t.stride(0), t.stride(1))
+
+
+def _index2d(t, what):
+    if t.dim() != 2 or t.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError(f"{what}: expect a 2-D int32/int64 tensor")
+    return t if t.stride(1) == 1 else t.contiguous()
+
+
+def extend_attention_cpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, req_to_tokens, b_req_idx, b_seq_len,
+                         b_seq_len_extend, b_start_loc_extend, max_len_extend, sm_scale, logit_cap):
+    for t, n in ((q_extend, "q_extend"), (k_extend, "k_extend"), (v_extend, "v_extend"), (o_extend, "o_extend"),
+                 (k_buffer, "k_buffer"), (v_buffer, "v_buffer")):
+        _thd(t, "extend_attention: " + n)
+    T, HQ, D = q_extend.shape
+    HKV, DV = k_extend.shape[1], v_extend.shape[2]
+    if k_extend.shape[2] != D or k_buffer.shape[2] != D or v_buffer.shape[2] != DV or tuple(o_extend.shape) != (T, HQ, DV):
+        raise RuntimeError("extend_attention: head-dim mismatch between q/k/v/o")
+    B = b_seq_len.shape[0]
+    rtt = _index2d(req_to_tokens, "extend_attention: req_to_tokens")
+    req = b_req_idx.to(torch.int64).contiguous()
+    seq = b_seq_len.to(torch.int64).contiguous()
+    ext = b_seq_len_extend.to(torch.int32).contiguous()
+    start = b_start_loc_extend.to(torch.int32).contiguous()
+    args = _lib.ExtendAttentionArgs(
+        q=q_extend.data_ptr(), k_extend=k_extend.data_ptr(), v_extend=v_extend.data_ptr(), k_buffer=k_buffer.data_ptr(),
+        v_buffer=v_buffer.data_ptr(), o=o_extend.data_ptr(), q_stride=_s2(q_extend), k_extend_stride=_s2(k_extend),
+        v_extend_stride=_s2(v_extend), k_buffer_stride=_s2(k_buffer), v_buffer_stride=_s2(v_buffer), o_stride=_s2(o_extend),
+        req_to_tokens=rtt.data_ptr(), req_to_tokens_stride=rtt.stride(0), req_to_tokens_is64=int(rtt.dtype == torch.int64),
+        b_req_idx=req.data_ptr(), b_seq_len=seq.data_ptr(), b_seq_len_extend=ext.data_ptr(),
+        b_start_loc_extend=start.data_ptr(), B=B, HQ=HQ, HKV=HKV, HBUF=k_buffer.shape[1], D=D, DV=DV,
+        max_len_extend=int(max_len_extend), sm_scale=float(sm_scale), logit_cap=float(logit_cap))
+    _lib.check(_lib.lib().sglk_extend_attention(ctypes.byref(args), _stream(q_extend)), "extend_attention_cpu")
+
+
+def decode_attention_cpu(query, k_buffer, v_buffer, output, key, value, loc, attn_logits, req_to_token, b_req_idx,
+                         b_seq_len, sm_scale, logit_cap):
+    for t, n in ((query, "query"), (k_buffer, "k_buffer"), (v_buffer, "v_buffer"), (output, "output"), (key, "key"),
+                 (value, "value")):
+        _thd(t, "decode_attention: " + n)
+    B, HQ, D = query.shape
+    HKV, DV = k_buffer.shape[1], v_buffer.shape[2]
+    if tuple(output.shape) != (B, HQ, DV) or tuple(key.shape) != (B, HKV, D) or tuple(value.shape) != (B, HKV, DV):
+        raise RuntimeError("decode_attention: shape mismatch")
+    if attn_logits.dim() != 4 or attn_logits.dtype != torch.float32 or not attn_logits.is_contiguous() \
+            or attn_logits.shape[0] != B or attn_logits.shape[1] != HQ or attn_logits.shape[3] != DV + 1:
+        raise RuntimeError("decode_attention: attn_logits must be contiguous f32 [B, HQ, splits, DV+1]")
+    if loc.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("decode_attention: loc must be int32/int64")
+    rtt = _index2d(req_to_token, "decode_attention: req_to_token")
+    req = b_req_idx.to(torch.int64).contiguous()
+    seq = b_seq_len.to(torch.int64).contiguous()
+    loc = loc.contiguous()
+    args = _lib.DecodeAttentionArgs(
+        q=query.data_ptr(), k_buffer=k_buffer.data_ptr(), v_buffer=v_buffer.data_ptr(), o=output.data_ptr(),
+        key=key.data_ptr(), value=value.data_ptr(), q_stride=_s2(query), k_buffer_stride=_s2(k_buffer),
+        v_buffer_stride=_s2(v_buffer), o_stride=_s2(output), key_stride=_s2(key), value_stride=_s2(value),
+        loc=loc.data_ptr(), loc_is64=int(loc.dtype == torch.int64), attn_logits=attn_logits.data_ptr(),
+        req_to_token=rtt.data_ptr(), req_to_token_stride=rtt.stride(0), req_to_token_is64=int(rtt.dtype == torch.int64),
+        b_req_idx=req.data_ptr(), b_seq_len=seq.data_ptr(), B=B, HQ=HQ, HKV=HKV, D=D, DV=DV,
+        splits=attn_logits.shape[2], sm_scale=float(sm_scale), logit_cap=float(logit_cap))
+    _lib.check(_lib.lib().sglk_decode_attention(ctypes.byref(args), _stream(query)), "decode_attention_cpu")
+
+
+_impl("extend_attention_cpu", extend_attention_cpu, lambda a, args: a is args[3])
+_impl("decode_attention_cpu", decode_attention_cpu, lambda a, args: a is args[1] or a is args[2] or a is args[3] or a is args[7])

@@ -238,8 +238,37 @@ def gen_rows():
              dict(rows=rows, two_d=two_d, dtype=str(dtype), seed=seed, input_sha256=checksum(inp["x"].view(torch.int16))))
 
 
+def gen_attn():
+    from torch.nn.functional import scaled_dot_product_attention
+    ns = lift("test_extend.py", ["_run_sdpa_forward_extend"], {"scaled_dot_product_attention": scaled_dot_product_attention})
+    for name, B, N_CTX, HQ, HKV, D, DV, mla, seed in recipes.EXTEND_CASES:
+        inp = recipes.extend_inputs(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+        o_ref = torch.empty(inp["q_extend"].shape[0], HQ, DV, dtype=torch.bfloat16)
+        ns["_run_sdpa_forward_extend"](inp["q_extend"], o_ref, inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"],
+                                       inp["b_req_idx"], inp["b_seq_len"], inp["b_prefix"], inp["b_extend"],
+                                       scaling=1.0 / D ** 0.5, enable_gqa=HQ != HKV, causal=True)
+        save("extend_" + name, {"ref_out": o_ref},
+             dict(B=B, HQ=HQ, HKV=HKV, D=D, DV=DV, mla=int(mla), seed=seed,
+                  input_sha256=checksum(inp["q_extend"], inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"])))
+    nsd = lift("test_mla.py", ["_run_sdpa_forward_decode"], {"scaled_dot_product_attention": scaled_dot_product_attention})
+    for name, B, HQ, HKV, D, DV, seq_len, v_alias, seed in recipes.DECODE_CASES:
+        inp = recipes.decode_inputs(B, HQ, HKV, D, DV, seq_len, v_alias, seed)
+        kb = inp["k_buffer"].clone()
+        if v_alias:
+            vb, value = kb.narrow(2, 0, DV), inp["key"].narrow(2, 0, DV)
+        else:
+            vb, value = inp["v_buffer"].clone(), inp["value"]
+            vb[inp["loc"]] = value      # the reference oracle only writes the key (MLA: v aliases k); GQA needs v too
+        o_ref = torch.zeros(B, HQ, DV, dtype=torch.bfloat16)
+        nsd["_run_sdpa_forward_decode"](inp["q"], o_ref, kb, vb, inp["key"], inp["loc"], inp["req_to_token"],
+                                        inp["b_req_idx"], inp["b_seq_len"], scaling=1.0 / D ** 0.5, enable_gqa=HQ != HKV)
+        save("decode_" + name, {"ref_out": o_ref},
+             dict(B=B, HQ=HQ, HKV=HKV, D=D, DV=DV, seq_len=seq_len, v_alias=int(v_alias), seed=seed,
+                  input_sha256=checksum(inp["q"], inp["k_buffer"], inp["key"], inp["loc"])))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared, "rows": gen_rows}
+            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(FAMILIES)

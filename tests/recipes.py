@@ -244,3 +244,75 @@ def norm_inputs(rows, hidden, dtype, seed):
 def act_inputs(rows, two_d, dtype, seed):
     g = _gen(seed)
     return dict(x=torch.randn(rows, two_d, generator=g).to(dtype))
+
+
+# ---- attention ---------------------------------------------------------------------------------------------------------
+# name, B, N_CTX, H_Q, H_KV, D, DV, mla(buffer has 1 head, no prefix), seed     (/root/reference/test_extend.py:190-198)
+EXTEND_CASES = [
+    ("b1_ctx23_hq8_hkv2", 1, 23, 8, 2, 128, 96, False, 7111),
+    ("b1_ctx123_hq16_hkv1_mla", 1, 123, 16, 1, 128, 96, True, 7112),
+    ("b4_ctx1230_hq16_hkv4", 4, 1230, 16, 4, 128, 96, False, 7113),
+    ("b4_ctx1230_hq16_hkv16_mla", 4, 1230, 16, 16, 128, 96, True, 7114),
+    ("b2_ctx700_hq32_hkv4_d128", 2, 700, 32, 4, 128, 128, False, 7115),       # Qwen3-30B-A3B attention heads
+    ("b2_ctx300_hq22_hkv22_d192", 2, 300, 22, 22, 192, 128, True, 7116),      # bench_extend.py:111-112 MLA prefill dims
+]
+# name, B, H_Q, H_KV, D, DV, seq_len, v_alias, seed      (/root/reference/test_mla.py:178-183, test_decoding.py:151-167)
+DECODE_CASES = [
+    ("mla_b1_s888", 1, 22, 1, 576, 512, 8 * 111, True, 7211),
+    ("mla_b4_s1024", 4, 22, 1, 576, 512, 8 * 128, True, 7212),
+    ("mla_b40_s1064", 40, 22, 1, 576, 512, 8 * 133, True, 7213),
+    ("gqa_b1_hq40_hkv8_s1024", 1, 40, 8, 128, 128, 1024, False, 7214),
+    ("gqa_b3_hq32_hkv4_s333", 3, 32, 4, 128, 128, 333, False, 7215),
+]
+
+
+def extend_inputs(B, N_CTX, H_Q, H_KV, D, DV, mla, seed):
+    """/root/reference/test_extend.py:79-138."""
+    g = _gen(seed)
+    dt = torch.bfloat16
+    prefix = torch.randint(1, max(N_CTX // 2, 2), (B,), generator=g, dtype=torch.int32)
+    if mla:
+        prefix.zero_()
+    extend = torch.randint(1, max(N_CTX // 2, 2), (B,), generator=g, dtype=torch.int32)
+    seq = prefix + extend
+    req_to_tokens = torch.zeros(B, int(seq.max()), dtype=torch.int32)
+    start = torch.zeros(B, dtype=torch.int32)
+    start[1:] = torch.cumsum(seq[:-1], 0)
+    start_ext = torch.zeros(B, dtype=torch.int32)
+    start_ext[1:] = torch.cumsum(extend[:-1], 0)
+    for i in range(B):
+        req_to_tokens[i, :seq[i]] = torch.arange(int(start[i]), int(start[i] + seq[i]))
+    total, ext_total = int(seq.sum()), int(extend.sum())
+    HB = 1 if mla else H_KV
+    k_buffer = torch.randn(total, HB, D, generator=g).to(dt)
+    v_buffer = torch.randn(total, HB, DV, generator=g).to(dt)
+    k_extend = torch.empty(ext_total, H_KV, D, dtype=dt)
+    v_extend = torch.empty(ext_total, H_KV, DV, dtype=dt)
+    q_extend = torch.randn(ext_total, H_Q, D, generator=g).to(dt)
+    for i in range(B):
+        s0, e0 = int(start[i] + prefix[i]), int(start[i] + seq[i])
+        s1, e1 = int(start_ext[i]), int(start_ext[i] + extend[i])
+        k_extend[s1:e1] = k_buffer[s0:e0]
+        v_extend[s1:e1] = v_buffer[s0:e0]
+    return dict(q_extend=q_extend, k_extend=k_extend, v_extend=v_extend, k_buffer=k_buffer, v_buffer=v_buffer,
+                req_to_tokens=req_to_tokens, b_req_idx=torch.arange(B, dtype=torch.int64), b_seq_len=seq.to(torch.int64),
+                b_prefix=prefix, b_extend=extend, b_start_loc_extend=start_ext)
+
+
+def decode_inputs(B, H_Q, H_KV, D, DV, seq_len, v_alias, seed):
+    """/root/reference/test_mla.py:68-105."""
+    g = _gen(seed)
+    dt = torch.bfloat16
+    total = B * seq_len
+    q = torch.randn(B, H_Q, D, generator=g).to(dt)
+    k_buffer = torch.randn(total, H_KV, D, generator=g).to(dt)
+    key = torch.randn(B, H_KV, D, generator=g).to(dt)
+    if v_alias:
+        v_buffer, value = None, None     # views of k_buffer / key are made by the caller
+    else:
+        v_buffer = torch.randn(total, H_KV, DV, generator=g).to(dt)
+        value = torch.randn(B, H_KV, DV, generator=g).to(dt)
+    loc = torch.randperm(total, generator=g)[:B].to(torch.int64)
+    req_to_token = torch.arange(total).reshape(B, seq_len).to(torch.int64)
+    return dict(q=q, k_buffer=k_buffer, v_buffer=v_buffer, key=key, value=value, loc=loc, req_to_token=req_to_token,
+                b_req_idx=torch.arange(B, dtype=torch.int64), b_seq_len=torch.full((B,), seq_len, dtype=torch.int64))

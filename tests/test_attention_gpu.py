@@ -1,0 +1,119 @@
+"""GPU parity of extend_attention_cpu / decode_attention_cpu through torch.ops.sgl_kernel.
+Pass predicates are the reference's: utils.compare on bf16 for extend (/root/reference/test_extend.py:188), cosine
+similarity > 0.99 + allclose(atol=3e-2) + bit-exact KV-cache update for decode (/root/reference/test_mla.py:169-175)."""
+import pytest
+import torch
+
+import recipes
+from conftest import load_golden
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sgl_kernel  # noqa: F401
+    assert torch.cuda.is_available()
+    return torch.ops.sgl_kernel
+
+
+def cuda(d):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("case", recipes.EXTEND_CASES, ids=lambda c: c[0])
+def test_extend_attention(ops, case):
+    name, B, N_CTX, HQ, HKV, D, DV, mla, seed = case
+    g, _ = load_golden("extend_" + name)
+    inp = recipes.extend_inputs(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+    d = cuda(inp)
+    o = torch.full((inp["q_extend"].shape[0], HQ, DV), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ret = ops.extend_attention_cpu(d["q_extend"], d["k_extend"], d["v_extend"], o, d["k_buffer"], d["v_buffer"],
+                                   d["req_to_tokens"], d["b_req_idx"], d["b_seq_len"], d["b_extend"],
+                                   d["b_start_loc_extend"], int(inp["b_extend"].max()), 1.0 / D ** 0.5, 0.0)
+    assert ret is None
+    assert torch.allclose(g["ref_out"], o.cpu(), rtol=1e-2, atol=1e-2), name
+    ref32 = oattn.extend_attention(inp["q_extend"], inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"], inp["b_req_idx"],
+                                   inp["b_seq_len"], inp["b_prefix"], inp["b_extend"], 1.0 / D ** 0.5)
+    err = (o.float().cpu() - ref32).norm() / ref32.norm()
+    assert err < 5e-3, f"{name}: relative RMS error {err:.2e}"
+
+
+def test_extend_attention_logit_cap_and_int64_pages(ops):
+    name, B, N_CTX, HQ, HKV, D, DV, mla, seed = recipes.EXTEND_CASES[0]
+    inp = recipes.extend_inputs(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+    d = cuda(inp)
+    o = torch.empty(inp["q_extend"].shape[0], HQ, DV, dtype=torch.bfloat16, device="cuda")
+    ops.extend_attention_cpu(d["q_extend"] * 4, d["k_extend"], d["v_extend"], o, d["k_buffer"], d["v_buffer"],
+                             d["req_to_tokens"].long(), d["b_req_idx"].int(), d["b_seq_len"].int(), d["b_extend"].long(),
+                             d["b_start_loc_extend"].long(), int(inp["b_extend"].max()), 1.0 / D ** 0.5, 5.0)
+    ref = oattn.extend_attention(inp["q_extend"] * 4, inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"], inp["b_req_idx"],
+                                 inp["b_seq_len"], inp["b_prefix"], inp["b_extend"], 1.0 / D ** 0.5, logit_cap=5.0)
+    assert torch.allclose(ref.bfloat16(), o.cpu(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("case", recipes.DECODE_CASES, ids=lambda c: c[0])
+def test_decode_attention(ops, case):
+    name, B, HQ, HKV, D, DV, seq_len, v_alias, seed = case
+    g, _ = load_golden("decode_" + name)
+    inp = recipes.decode_inputs(B, HQ, HKV, D, DV, seq_len, v_alias, seed)
+    kb = inp["k_buffer"].cuda()
+    key = inp["key"].cuda()
+    if v_alias:          # exactly the reference's aliasing: v is a narrow view of k (test_mla.py:83,91)
+        vb, value = kb.narrow(2, 0, DV), key.narrow(2, 0, DV)
+    else:
+        vb, value = inp["v_buffer"].cuda(), inp["value"].cuda()
+    o = torch.zeros(B, HQ, DV, dtype=torch.bfloat16, device="cuda")
+    logits = torch.empty(B, HQ, 8, DV + 1, dtype=torch.float32, device="cuda")
+    ret = ops.decode_attention_cpu(inp["q"].cuda(), kb, vb, o, key, value, inp["loc"].cuda(), logits,
+                                   inp["req_to_token"].cuda(), inp["b_req_idx"].cuda(), inp["b_seq_len"].cuda(),
+                                   1.0 / D ** 0.5, 0.0)
+    assert ret is None
+    ref = g["ref_out"].float()
+    cos = torch.nn.functional.cosine_similarity(o.float().cpu().flatten(), ref.flatten(), dim=0)
+    assert cos > 0.99, f"{name}: cos_sim {cos}"
+    assert torch.allclose(o.cpu().float(), ref, atol=3e-2), name
+    # KV-cache update is bit-exact and touches nothing else
+    expect_k = inp["k_buffer"].clone()
+    expect_k[inp["loc"]] = inp["key"]
+    assert torch.equal(kb.cpu(), expect_k)
+    if not v_alias:
+        expect_v = inp["v_buffer"].clone()
+        expect_v[inp["loc"]] = inp["value"]
+        assert torch.equal(vb.cpu(), expect_v)
+    # tighter: against the fp32 oracle
+    kb2 = inp["k_buffer"].clone()
+    vb2 = kb2.narrow(2, 0, DV) if v_alias else inp["v_buffer"].clone()
+    ref32 = oattn.decode_attention(inp["q"], kb2, vb2, inp["key"], inp["key"].narrow(2, 0, DV) if v_alias else inp["value"],
+                                   inp["loc"], inp["req_to_token"], inp["b_req_idx"], inp["b_seq_len"], 1.0 / D ** 0.5)
+    err = (o.float().cpu() - ref32).norm() / ref32.norm()
+    assert err < 6e-3, f"{name}: relative RMS error {err:.2e}"
+
+
+def test_decode_attention_ragged_lengths_and_int32_index(ops):
+    """Different sequence lengths per request (some shorter than the split count), int32 page table and loc."""
+    B, HQ, HKV, D, DV = 5, 16, 2, 128, 128
+    lens = [1, 5, 64, 200, 777]
+    L = max(lens)
+    g = torch.Generator().manual_seed(12)
+    total = B * L
+    q = torch.randn(B, HQ, D, generator=g).bfloat16()
+    kb = torch.randn(total, HKV, D, generator=g).bfloat16()
+    vb = torch.randn(total, HKV, DV, generator=g).bfloat16()
+    key = torch.randn(B, HKV, D, generator=g).bfloat16()
+    value = torch.randn(B, HKV, DV, generator=g).bfloat16()
+    perm = torch.randperm(total, generator=g)
+    rtt = perm.view(B, L).to(torch.int32)
+    seq = torch.tensor(lens)
+    loc = torch.stack([rtt[b, lens[b] - 1] for b in range(B)]).to(torch.int32)   # the new token is the last position
+    o = torch.zeros(B, HQ, DV, dtype=torch.bfloat16, device="cuda")
+    logits = torch.empty(B, HQ, 8, DV + 1, dtype=torch.float32, device="cuda")
+    kbd, vbd = kb.cuda(), vb.cuda()
+    ops.decode_attention_cpu(q.cuda(), kbd, vbd, o, key.cuda(), value.cuda(), loc.cuda(), logits, rtt.cuda(),
+                             torch.arange(B).cuda(), seq.cuda(), 1.0 / D ** 0.5, 0.0)
+    kb2, vb2 = kb.clone(), vb.clone()
+    ref = oattn.decode_attention(q, kb2, vb2, key, value, loc, rtt, torch.arange(B), seq, 1.0 / D ** 0.5)
+    assert torch.equal(kbd.cpu(), kb2) and torch.equal(vbd.cpu(), vb2)
+    assert torch.allclose(o.cpu().float(), ref, atol=3e-2)
+    assert (o.float().cpu() - ref).norm() / ref.norm() < 6e-3

@@ -229,3 +229,31 @@ def test_oracle_silu_and_mul(case):
     name, rows, two_d, dtype, seed = case
     g, _ = load_golden("act_" + name)
     assert torch.equal(oew.silu_and_mul(recipes.act_inputs(rows, two_d, dtype, seed)["x"]), g["ref_out"])
+
+
+# ---- attention -----------------------------------------------------------------------------------------------------------
+from oracle import attention as oattn  # noqa: E402
+
+
+@pytest.mark.parametrize("case", recipes.EXTEND_CASES[:4], ids=lambda c: c[0])
+def test_oracle_extend_attention(case):
+    name, B, N_CTX, HQ, HKV, D, DV, mla, seed = case
+    g, _ = load_golden("extend_" + name)
+    inp = recipes.extend_inputs(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+    out = oattn.extend_attention(inp["q_extend"], inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"], inp["b_req_idx"],
+                                 inp["b_seq_len"], inp["b_prefix"], inp["b_extend"], 1.0 / D ** 0.5)
+    assert moe.allclose_ref(g["ref_out"], out.bfloat16())
+
+
+@pytest.mark.parametrize("case", [recipes.DECODE_CASES[0], recipes.DECODE_CASES[4]], ids=lambda c: c[0])
+def test_oracle_decode_attention(case):
+    name, B, HQ, HKV, D, DV, seq_len, v_alias, seed = case
+    g, _ = load_golden("decode_" + name)
+    inp = recipes.decode_inputs(B, HQ, HKV, D, DV, seq_len, v_alias, seed)
+    kb = inp["k_buffer"].clone()
+    vb = kb.narrow(2, 0, DV) if v_alias else inp["v_buffer"].clone()
+    value = inp["key"].narrow(2, 0, DV) if v_alias else inp["value"]
+    out = oattn.decode_attention(inp["q"], kb, vb, inp["key"], value, inp["loc"], inp["req_to_token"], inp["b_req_idx"],
+                                 inp["b_seq_len"], 1.0 / D ** 0.5)
+    assert torch.allclose(out.bfloat16().float(), g["ref_out"].float(), atol=3e-2)      # test_mla.py:173
+    assert torch.equal(kb[inp["loc"]], inp["key"])
