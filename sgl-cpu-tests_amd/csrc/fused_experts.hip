@@ -20,25 +20,34 @@ struct Workspace {
     size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, xq, xs, ic1q, ic1s, total;
 };
 
-// tile height of the tuned grouped GEMMs: 256-row tiles once experts see enough rows to fill them, else 128
+// Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E):
+//   <  44 rows : 32-token tiles, weight-streaming kernel (HBM-bound regime: every touched expert's weights are read once;
+//                measured crossover against the 256 kernel at Qwen3 dims: M ~ 700)
+//   >= 44 rows : 256-token tiles, 8-wave LDS-DMA ring kernel (faster than 128-row tiles at every M measured, 768..8192)
+//   shapes the two cannot take (K % 256, very large operands): 128-token tiles
 int pick_tile_m(int M, int N, int K, int E, int topk) {
     const char* force = getenv("SGLK_MOE_TILE_M");
     const int64_t S = (int64_t)M * topk;
     // the 256 kernel addresses its operands through 32-bit buffer offsets
     const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && S * (int64_t)N * 2 < (1ll << 32) &&
                        (int64_t)M * K * 2 < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32);
+    // stream kernel: both reduction lengths (K for GEMM-1, N for GEMM-2) must be multiples of 256 (ring of 8 pieces)
+    const bool ok_stream = (K % 256 == 0) && (N % 256 == 0) && (int64_t)kStreamTileM * K * 2 <= 150 * 1024 &&
+                           (int64_t)kStreamTileM * N * 2 <= 150 * 1024;
     if (force) {
         const int f = atoi(force);
         if (f == 256 && ok256) return 256;
+        if (f == 32 && ok_stream) return kStreamTileM;
         if (f == 128) return 128;
     }
-    return (ok256 && S >= (int64_t)192 * E) ? 256 : kTileM;
+    if (ok_stream && S < (int64_t)44 * E) return kStreamTileM;
+    return ok256 ? 256 : kTileM;
 }
 
 Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     Workspace w{};
     const int64_t S = (int64_t)M * topk;
-    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kGenericTileM);   // the smallest tile bounds the table size
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, kStreamTileM);   // the smallest tile bounds the table size
     size_t off = 0;
     auto take = [&](size_t bytes) {
         size_t o = off;
@@ -156,12 +165,13 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g1.n_half = N;
         g1.tile_info = (const int4*)tile_info;
         g1.num_tiles = num_tiles;
-        g1.n_tiles = tile_m == 256 ? N / 128 : N / 64;
+        g1.n_tiles = tile_m == 128 ? N / 64 : N / 128;
         g1.out = ic1;
         g1.out_stride = N;
         g1.topk_weights = nullptr;
         rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s)
-                           : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
+             : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_GATE_UP, g1, max_tiles, s)
+                                      : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
 
@@ -181,12 +191,13 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.n_half = 0;
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
-        g2.n_tiles = tile_m == 256 ? K / 256 : K / 128;
+        g2.n_tiles = tile_m == 128 ? K / 128 : K / 256;
         g2.out = ic2;
         g2.out_stride = K;
         g2.topk_weights = a->topk_weights;
         rc = tile_m == 256 ? launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s)
-                           : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
+             : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)
+                                      : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else {

@@ -4,7 +4,8 @@
 
 namespace sglk {
 
-constexpr int kTileM = 128;   // tokens (slot rows) per grouped-GEMM tile
+constexpr int kTileM = 128;        // tokens (slot rows) per tile of the 128x128 kernel
+constexpr int kStreamTileM = 32;   // tokens per tile of the weight-streaming small-M kernel
 
 enum { MODE_GATE_UP = 0, MODE_DOWN = 1 };
 
@@ -77,6 +78,9 @@ int launch_quant_int8_rows(const uint16_t* x, int64_t x_stride, int8_t* q, int64
 
 int launch_quant_int8_rows_f32(const float* x, int64_t x_stride, int8_t* q, int64_t q_stride, float* scale,
                                int64_t rows, int cols, float floor, hipStream_t stream);
+
+// 32-token tiles, weights streamed global -> VGPR (moe_gemm_fp8w_stream.hip); tile table built with tile_m = 32
+int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,

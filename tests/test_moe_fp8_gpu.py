@@ -147,7 +147,7 @@ def test_cpu_tensors_are_staged_through_the_gpu(ops):
     check_close(out, g["ref_out_f32"], "cpu-staged")
 
 
-@pytest.mark.parametrize("tile_m", ["128", "256"])
+@pytest.mark.parametrize("tile_m", ["32", "128", "256"])
 @pytest.mark.parametrize("block", [(128, 128), (64, 128)])
 def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
     """Both grouped-GEMM tilings (128-row 2-stage, 256-row 3-deep ring) against the plain-C oracle; ragged expert

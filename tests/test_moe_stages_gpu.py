@@ -89,7 +89,8 @@ def align_oracle(ids, E, tile_m):
 
 
 @pytest.mark.parametrize("M,E,topk,masked", [(1, 8, 2, False), (14, 8, 8, True), (777, 128, 8, False),
-                                             (4096, 128, 8, True), (3, 1024, 2, False), (20000, 16, 4, False)])
+                                             (4096, 128, 8, True), (3, 1024, 2, False), (20000, 16, 4, False),
+                                             (1024, 128, 8, True), (1025, 256, 8, False), (130, 200, 7, True), (64, 128, 8, False)])
 def test_moe_align_bit_exact(L, M, E, topk, masked):
     g = torch.Generator().manual_seed(M * 131 + E)
     ids = torch.randint(0, E, (M, topk), generator=g, dtype=torch.int32)

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench.py): the M sweep of fp8 fused_experts and the other
+operators of SURVEY.md §8 at the shapes the reference benches, each against the roofline that bounds it.
+
+    python tools/bench_ops.py [moe|gemm|attn|rows|all] > gpurun_out/bench_ops.json
+
+Prints one JSON object per line.  HIP-event timing on the current stream, warm-up, rotating clones where the working
+set would otherwise sit in the 256 MiB Infinity Cache.
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
+
+import torch  # noqa: E402
+
+import sgl_kernel  # noqa: E402,F401
+
+ops = torch.ops.sgl_kernel
+PEAK_BF16, PEAK_HBM = 2500.0, 8000.0   # TFLOP/s dense bf16 MFMA, GB/s (MI355X_MICROARCH.md)
+
+
+def timed(fn, iters, warm=3):
+    for _ in range(warm):
+        fn(0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters   # ms
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def bench_moe():
+    K, N, E, topk = 2048, 768, 128, 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w1 = (torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+    w2 = (torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+    w1s = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3
+    w2s = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
+    w1p = [ops.convert_weight_packed(w1)]
+    w2p = [ops.convert_weight_packed(w2)]
+    w1p.append(w1p[0].clone())
+    w2p.append(w2p[0].clone())
+    del w1, w2
+    for M in (1, 4, 16, 64, 256, 512, 1024, 2048, 3929, 4096, 8192, 16384, 32768):
+        a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        score = torch.softmax(torch.randn(M, E, device="cuda", generator=g).bfloat16(), dim=-1, dtype=torch.float32)
+        tw, ids = torch.topk(score, topk)
+        ids = ids.to(torch.int32)
+        touched = int(torch.unique(ids).numel())
+        ms = timed(lambda i: ops.fused_experts_cpu(a, w1p[i & 1], w2p[i & 1], tw, ids, False, False, True, w1s, w2s,
+                                                   [128, 128], None, None, True), 20 if M >= 4096 else 50)
+        flop = M * topk * 6 * N * K
+        byts = touched * 3 * N * K + 4 * M * K + 8 * M * topk      # weights of the touched experts + in/out
+        t_mfma, t_hbm = flop / (PEAK_BF16 * 1e12), byts / (PEAK_HBM * 1e9)
+        emit(op="fused_experts_fp8", M=M, experts_touched=touched, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
+             tokens_per_s=round(M / ms * 1e3), algorithmic_gb=round(byts / 1e9, 4), gbps=round(byts / ms / 1e6, 1),
+             bound="mfma" if t_mfma > t_hbm else "hbm", roofline_frac=round(max(t_mfma, t_hbm) * 1e3 / ms, 4))
+
+
+def bench_gemm():
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for (M, N, K) in ((1000, 18432, 2560), (128, 4096, 4096), (4096, 1536, 2048)):   # bench_gemm.py:147, config 0, Qwen3 gate_up
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        wb = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+        wf = (torch.randn(N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+        wi = torch.randint(-127, 127, (N, K), device="cuda", generator=g, dtype=torch.int8)
+        sc = torch.randn(N // 128, K // 128, device="cuda", generator=g) * 1e-3
+        si = torch.rand(N, device="cuda", generator=g) * 1e-2
+        flop = 2 * M * N * K
+        for name, fn in (
+                ("weight_packed_linear_bf16", lambda i: ops.weight_packed_linear(x, wb, None, False)),
+                ("fp8_scaled_mm", lambda i: ops.fp8_scaled_mm_cpu(x, wf, sc, [128, 128], None, torch.bfloat16, False)),
+                ("int8_scaled_mm_with_quant", lambda i: ops.int8_scaled_mm_with_quant(x, wi, si, None, torch.bfloat16, False))):
+            ms = timed(fn, 10)
+            emit(op=name, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
+                 roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma", engine="generic")
+
+
+def bench_attn():
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dt = torch.bfloat16
+    for (B, CTX, HQ, HKV, D, DV) in ((1, 4096, 32, 4, 128, 128), (1, 8192, 16, 2, 128, 128), (4, 2048, 22, 22, 192, 128)):
+        T = B * CTX
+        q = torch.randn(T, HQ, D, device="cuda", generator=g).to(dt)
+        k = torch.randn(T, HKV, D, device="cuda", generator=g).to(dt)
+        v = torch.randn(T, HKV, DV, device="cuda", generator=g).to(dt)
+        o = torch.empty(T, HQ, DV, device="cuda", dtype=dt)
+        rtt = torch.arange(T, device="cuda", dtype=torch.int32).view(B, CTX)
+        seq = torch.full((B,), CTX, device="cuda", dtype=torch.int64)
+        ext = torch.full((B,), CTX, device="cuda", dtype=torch.int32)
+        start = (torch.arange(B, device="cuda", dtype=torch.int32) * CTX)
+        ms = timed(lambda i: ops.extend_attention_cpu(q, k, v, o, k, v, rtt, torch.arange(B, device="cuda"), seq, ext, start,
+                                                      CTX, 1.0 / D ** 0.5, 0.0), 10)
+        flop = B * HQ * (CTX * CTX / 2) * 2 * (D + DV)     # causal
+        emit(op="extend_attention", B=B, ctx=CTX, HQ=HQ, HKV=HKV, D=D, DV=DV, ms=round(ms, 4),
+             tflops=round(flop / ms / 1e9, 2), roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
+    for (B, HQ, HKV, D, DV, S, alias) in ((1, 22, 1, 576, 512, 1024, True), (40, 22, 1, 576, 512, 1064, True),
+                                            (128, 22, 1, 576, 512, 4096, True), (64, 32, 4, 128, 128, 4096, False)):
+        total = B * S
+        q = torch.randn(B, HQ, D, device="cuda", generator=g).to(dt)
+        kb = torch.randn(total, HKV, D, device="cuda", generator=g).to(dt)
+        key = torch.randn(B, HKV, D, device="cuda", generator=g).to(dt)
+        vb = kb.narrow(2, 0, DV) if alias else torch.randn(total, HKV, DV, device="cuda", generator=g).to(dt)
+        val = key.narrow(2, 0, DV) if alias else torch.randn(B, HKV, DV, device="cuda", generator=g).to(dt)
+        o = torch.empty(B, HQ, DV, device="cuda", dtype=dt)
+        logits = torch.empty(B, HQ, 8, DV + 1, device="cuda", dtype=torch.float32)
+        rtt = torch.arange(total, device="cuda").view(B, S)
+        loc = rtt[:, -1].contiguous()
+        seq = torch.full((B,), S, device="cuda", dtype=torch.int64)
+        ms = timed(lambda i: ops.decode_attention_cpu(q, kb, vb, o, key, val, loc, logits, rtt, torch.arange(B, device="cuda"),
+                                                      seq, 1.0 / D ** 0.5, 0.0), 20)
+        byts = total * HKV * (D if alias else D + DV) * 2
+        emit(op="decode_attention", B=B, HQ=HQ, HKV=HKV, D=D, DV=DV, seq=S, v_alias=alias, ms=round(ms, 4),
+             gbps=round(byts / ms / 1e6, 1), roofline_frac=round(byts / ms / 1e6 / PEAK_HBM, 4), bound="hbm")
+
+
+def bench_rows():
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for rows, two_d in ((128, 22016), (1000, 18432 * 2), (17, 36864)):
+        x = torch.randn(rows, two_d, device="cuda", generator=g).bfloat16()
+        ms = timed(lambda i: ops.silu_and_mul_cpu(x), 50)
+        byts = rows * two_d * 2 * 1.5
+        emit(op="silu_and_mul", rows=rows, two_d=two_d, ms=round(ms, 5), gbps=round(byts / ms / 1e6, 1),
+             roofline_frac=round(byts / ms / 1e6 / PEAK_HBM, 4), bound="hbm")
+    for rows, h in ((1024, 4096), (16384, 2048), (1, 5120)):
+        x = torch.randn(rows, h, device="cuda", generator=g).bfloat16()
+        r = torch.randn(rows, h, device="cuda", generator=g).bfloat16()
+        w = torch.randn(h, device="cuda", generator=g).bfloat16()
+        o = torch.empty_like(x)
+        ms = timed(lambda i: ops.rmsnorm_cpu(o, x, w, 1e-6), 50)
+        emit(op="rmsnorm", rows=rows, hidden=h, ms=round(ms, 5), gbps=round(rows * h * 4 / ms / 1e6, 1),
+             roofline_frac=round(rows * h * 4 / ms / 1e6 / PEAK_HBM, 4), bound="hbm")
+        ms = timed(lambda i: ops.fused_add_rmsnorm_cpu(x, r, w, 1e-6), 50)
+        emit(op="fused_add_rmsnorm", rows=rows, hidden=h, ms=round(ms, 5), gbps=round(rows * h * 8 / ms / 1e6, 1),
+             roofline_frac=round(rows * h * 8 / ms / 1e6 / PEAK_HBM, 4), bound="hbm")
+    for M, E, G, k, tg in ((16384, 128, 1, 8, 1), (4096, 256, 8, 8, 4)):
+        gate = torch.randn(M, E, device="cuda", generator=g).bfloat16()
+        ms = timed(lambda i: ops.grouped_topk_cpu(gate, gate, k, True, G, tg, 0, None, None), 50)
+        emit(op="grouped_topk", M=M, E=E, G=G, topk=k, ms=round(ms, 5), tokens_per_s=round(M / ms * 1e3))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    table = {"moe": bench_moe, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
+    for name, fn in table.items():
+        if which in ("all", name):
+            fn()
