@@ -28,11 +28,14 @@ struct MoeGemmParams {
     uint16_t* out;                // GATE_UP: ic1 [position][N];  DOWN: ic2 [slot][K]
     int64_t out_stride;
     const float* topk_weights;    // DOWN only
+    unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
 int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 // 256-token x 256-row tiles, 8 waves, 3-deep LDS-DMA ring (moe_gemm_fp8w_256.hip); tile table built with tile_m = 256
 int launch_moe_gemm_fp8w_256(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+// same tiling on mfma_f32_32x32x16_bf16 (moe_gemm_fp8w_256x.hip); needs block_n % 32 == 0
+int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
 constexpr int kGenericTileM = 64;
