@@ -1,4 +1,6 @@
 // Dense entry points of the C-ABI built on the generic engine: shared_expert, scaled_mm (fp8 / int8 / bf16 weights).
+#include <stdlib.h>
+
 #include "moe_internal.h"
 
 using namespace sglk;
@@ -6,8 +8,33 @@ using namespace sglk;
 namespace {
 
 struct DenseWs {
-    size_t tile_info, num_tiles, ic1, xq, xs, ic1q, ic1s, total;
+    size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, total;
 };
+
+// the tuned 256-token fp8 kernel (moe_gemm_fp8w_256x.hip) takes a dense [M][C] x [R][C]^T when this holds
+bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int block_k, const void* x, int64_t x_stride) {
+    return wtype == SGLK_W_FP8_E4M3 && packed && M >= 192 && R % 256 == 0 && C % 128 == 0 && (C >> 7) <= 64 &&
+           block_k == 128 && block_n % 32 == 0 && x_stride % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+           (int64_t)M * x_stride * 2 < (1ll << 32) && (int64_t)R * C < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+}
+
+void fill_tuned(MoeGemmParams& g, const void* x, int64_t x_stride, int M, const int* ident, const void* w,
+                const float* scale, int R, int C, int block_n, const int4* tile_info, const int* num_tiles) {
+    g.x = (const uint16_t*)x;
+    g.x_stride = x_stride;
+    g.x_bytes = (int64_t)M * x_stride * 2;
+    g.sorted_slot = ident;
+    g.topk = 1;
+    g.w = (const uint8_t*)w;
+    g.w_expert_stride = (int64_t)R * C;
+    g.w_scale = scale;
+    g.scale_rows = (int)ceil_div(R, block_n);
+    g.scale_cols = C / 128;
+    g.block_n = block_n;
+    g.C = C;
+    g.tile_info = tile_info;
+    g.num_tiles = num_tiles;
+}
 
 DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
     DenseWs w{};
@@ -20,6 +47,7 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
     const int tiles = (int)ceil_div(M > 0 ? M : 1, kGenericTileM);
     w.tile_info = take((size_t)tiles * 16);
     w.num_tiles = take(4);
+    w.ident = take((size_t)(M > 0 ? M : 1) * 4);
     if (need_ic1) w.ic1 = take((size_t)M * N * (int8_act ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until quantised
     if (int8_act) {
         w.xq = take((size_t)M * K);
@@ -99,8 +127,35 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
     uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
+    if ((a->packed & 3) == 3 && N % 128 == 0 &&
+        tuned_dense_ok(M, K, N, a->wtype, 1, a->block_n, a->block_k, ic1, N) &&
+        tuned_dense_ok(M, 2 * N, K, a->wtype, 1, a->block_n, a->block_k, a->hidden, a->hidden_stride) &&
+        a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && a->fused_out_stride % 4 == 0) {
+        // large fp8 shared expert on the tuned grouped-GEMM kernel (one "expert", identity row map)
+        int* ident = (int*)(ws + w.ident);
+        const int t256 = (int)ceil_div(M, 256);
+        rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
+        if (rc != SGLK_OK) return rc;
+        MoeGemmParams t1{};
+        fill_tuned(t1, a->hidden, a->hidden_stride, M, ident, a->w1, a->w1_scale, 2 * N, K, a->block_n, tile_info, num_tiles);
+        t1.n_half = N;
+        t1.n_tiles = N / 128;
+        t1.out = ic1;
+        t1.out_stride = N;
+        rc = launch_moe_gemm_fp8w_256x(MODE_GATE_UP, t1, t256, s);
+        if (rc != SGLK_OK) return rc;
+        MoeGemmParams t2{};
+        fill_tuned(t2, ic1, N, M, ident, a->w2, a->w2_scale, K, N, a->block_n, tile_info, num_tiles);
+        t2.n_tiles = K / 256;
+        t2.out = (uint16_t*)a->out;
+        t2.out_stride = a->out_stride;
+        t2.addend = (const uint16_t*)a->fused_out;
+        t2.addend_stride = a->fused_out_stride;
+        t2.addend_scale = a->routed_scaling_factor;
+        return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t2, t256, s);
+    }
     const int tiles = (int)ceil_div(M, kGenericTileM);
-    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, s);
+    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
     if (rc != SGLK_OK) return rc;
 
     GenericGemmParams g1{};
@@ -186,8 +241,23 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     unsigned char* ws = (unsigned char*)a->workspace;
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
+    if (a->out_type == SGLK_OUT_BF16 && !a->x_is_int8 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 &&
+        (!a->bias || ((uintptr_t)a->bias % 16) == 0) &&
+        tuned_dense_ok(M, N, K, a->wtype, a->packed, a->block_n, a->block_k, a->x, a->x_stride)) {
+        int* ident = (int*)(ws + w.ident);
+        const int t256 = (int)ceil_div(M, 256);
+        rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
+        if (rc != SGLK_OK) return rc;
+        MoeGemmParams t{};
+        fill_tuned(t, a->x, a->x_stride, M, ident, a->w, a->w_scale, N, K, a->block_n, tile_info, num_tiles);
+        t.n_tiles = N / 256;
+        t.out = (uint16_t*)a->out;
+        t.out_stride = a->out_stride;
+        t.bias = a->bias;
+        return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t, t256, s);
+    }
     const int tiles = (int)ceil_div(M, kGenericTileM);
-    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, s);
+    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
     if (rc != SGLK_OK) return rc;
 
     GenericGemmParams g{};

@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
 }  // namespace gg
 
 // m-tile table of a dense [M] x ... problem: one "expert", rows in natural order
-__global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_tiles) {
+__global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots) {
     const int n = (M + tile_m - 1) / tile_m;
+    if (identity_slots)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) identity_slots[i] = i;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int rows = M - i * tile_m < tile_m ? M - i * tile_m : tile_m;
         tile_info[i] = make_int4(0, i * tile_m, rows, 0);
@@ -269,12 +271,12 @@ __global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_
     if (blockIdx.x == 0 && threadIdx.x == 0) num_tiles[0] = n;
 }
 
-int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, hipStream_t stream) {
-    const int n = (M + tile_m - 1) / tile_m;
+int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream) {
+    const int n = identity_slots ? M : (M + tile_m - 1) / tile_m;
     int blocks = (n + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(dense_tiles_kernel, dim3(blocks), dim3(256), 0, stream, M, tile_m, tile_info, num_tiles);
+    hipLaunchKernelGGL(dense_tiles_kernel, dim3(blocks), dim3(256), 0, stream, M, tile_m, tile_info, num_tiles, identity_slots);
     SGLK_CHECK_LAUNCH("dense_tiles");
     return SGLK_OK;
 }

@@ -407,16 +407,33 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
                 }
             }
         } else {
-            float tw = 0.f;
-            if (r < rows) tw = p.topk_weights[p.sorted_slot[pos0 + r]];
+            float tw = 1.f;
+            if (MODE == MODE_DOWN) tw = (r < rows) ? p.topk_weights[p.sorted_slot[pos0 + r]] : 0.f;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const float sc_w = mant[rt] * tw;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    float o4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i] * sc_w;
+                    if (MODE == MODE_PLAIN) {   // dense epilogue: + bias[col] + addend[row][col] * scale, in fp32
+                        const int gc = ntile * kCols + wn * 64 + rt * 32 + rg * 8 + h * 4;
+                        if (p.bias) {
+                            const float4 b = *reinterpret_cast<const float4*>(p.bias + gc);
+                            o4[0] += b.x; o4[1] += b.y; o4[2] += b.z; o4[3] += b.w;
+                        }
+                        if (p.addend && r < rows) {
+                            const uint2 a = *reinterpret_cast<const uint2*>(p.addend + (int64_t)(pos0 + r) * p.addend_stride + gc);
+                            o4[0] += __uint_as_float(a.x << 16) * p.addend_scale;
+                            o4[1] += __uint_as_float(a.x & 0xffff0000u) * p.addend_scale;
+                            o4[2] += __uint_as_float(a.y << 16) * p.addend_scale;
+                            o4[3] += __uint_as_float(a.y & 0xffff0000u) * p.addend_scale;
+                        }
+                    }
                     uint2 v;
-                    v.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w, acc[rt][tt][rg * 4 + 1] * sc_w);
-                    v.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w, acc[rt][tt][rg * 4 + 3] * sc_w);
+                    v.x = pack_bf16x2(o4[0], o4[1]);
+                    v.y = pack_bf16x2(o4[2], o4[3]);
                     const int col = wn * 64 + rt * 32 + rg * 8 + h * 4;
                     const int chunk = (col >> 3) ^ (r & 15);
                     *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
@@ -437,8 +454,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
         if (r < rows) {
             const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
             int64_t orow;
-            if (MODE == MODE_GATE_UP) orow = (int64_t)(pos0 + r) * p.out_stride + ntile * kCols;
-            else orow = (int64_t)p.sorted_slot[pos0 + r] * p.out_stride + ntile * kCols;
+            if (MODE == MODE_DOWN) orow = (int64_t)p.sorted_slot[pos0 + r] * p.out_stride + ntile * kCols;
+            else orow = (int64_t)(pos0 + r) * p.out_stride + ntile * kCols;
             *reinterpret_cast<uint4*>(p.out + orow + lc * 8) = v;
         }
     }
@@ -450,6 +467,11 @@ int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, 
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
     if ((p.C >> 7) > g256x::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
+    if (mode == MODE_PLAIN) {
+        hipLaunchKernelGGL((g256x::moe_gemm_fp8w_256x_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+        SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256x");
+        return SGLK_OK;
+    }
 #define SGLK_LAUNCH256X(R)                                                                                             \
     if (mode == MODE_GATE_UP)                                                                                          \
         hipLaunchKernelGGL((g256x::moe_gemm_fp8w_256x_kernel<MODE_GATE_UP, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \

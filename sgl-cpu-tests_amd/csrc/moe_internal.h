@@ -7,7 +7,7 @@ namespace sglk {
 constexpr int kTileM = 128;        // tokens (slot rows) per tile of the 128x128 kernel
 constexpr int kStreamTileM = 32;   // tokens per tile of the weight-streaming small-M kernel
 
-enum { MODE_GATE_UP = 0, MODE_DOWN = 1 };
+enum { MODE_GATE_UP = 0, MODE_DOWN = 1, MODE_PLAIN = 2 };   // PLAIN: out[pos] = x.W^T (+bias) (+addend*scale), dense
 
 struct MoeGemmParams {
     const uint16_t* x;            // activations, bf16 bits
@@ -28,6 +28,10 @@ struct MoeGemmParams {
     uint16_t* out;                // GATE_UP: ic1 [position][N];  DOWN: ic2 [slot][K]
     int64_t out_stride;
     const float* topk_weights;    // DOWN only
+    const float* bias;            // PLAIN: [output columns] f32 or null
+    const uint16_t* addend;       // PLAIN: bf16 [rows][out columns] added as addend * addend_scale, or null
+    int64_t addend_stride;
+    float addend_scale;
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
@@ -74,7 +78,8 @@ struct GenericGemmParams {
 };
 
 int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream);
-int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, hipStream_t stream);
+// m-tile table of a dense problem (one "expert"); identity_slots (optional, [M]) = 0..M-1 for the tuned kernels' row lookup
+int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream);
 // per-row symmetric int8 quantisation: q = rint(x * 127/amax), scale = amax/127, amax = max(|row|, floor)
 int launch_quant_int8_rows(const uint16_t* x, int64_t x_stride, int8_t* q, int64_t q_stride, float* scale, int64_t rows,
                            int cols, float floor, hipStream_t stream);

@@ -145,6 +145,8 @@ GEMM_FP8_CASES = [
     ("m111_n192_k640", 111, 192, 640, False, False, 4212),
     ("m14_n192_k768_bias_chunk", 14, 192, 768, True, True, 4213),
     ("m64_n2816_k1024_bias", 64, 2816, 1024, True, False, 4214),
+    ("m500_n768_k1024_bias", 500, 768, 1024, True, False, 4215),      # large enough for the tuned 256-token kernel
+    ("m333_n512_k2048_chunk", 333, 512, 2048, False, True, 4216),
 ]
 # name, M, N, K, has_bias, seed           bf16 weight_packed_linear (/root/reference/test_gemm.py:30-33)
 GEMM_BF16_CASES = [

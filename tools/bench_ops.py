@@ -75,15 +75,17 @@ def bench_gemm():
         wf = (torch.randn(N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
         wi = torch.randint(-127, 127, (N, K), device="cuda", generator=g, dtype=torch.int8)
         sc = torch.randn(N // 128, K // 128, device="cuda", generator=g) * 1e-3
+        wfp = ops.convert_weight_packed(wf)          # the reference benches prepacked weights (bench_gemm.py:64-69)
         si = torch.rand(N, device="cuda", generator=g) * 1e-2
         flop = 2 * M * N * K
         for name, fn in (
                 ("weight_packed_linear_bf16", lambda i: ops.weight_packed_linear(x, wb, None, False)),
-                ("fp8_scaled_mm", lambda i: ops.fp8_scaled_mm_cpu(x, wf, sc, [128, 128], None, torch.bfloat16, False)),
+                ("fp8_scaled_mm_packed", lambda i: ops.fp8_scaled_mm_cpu(x, wfp, sc, [128, 128], None, torch.bfloat16, True)),
+                ("fp8_scaled_mm_rowmajor", lambda i: ops.fp8_scaled_mm_cpu(x, wf, sc, [128, 128], None, torch.bfloat16, False)),
                 ("int8_scaled_mm_with_quant", lambda i: ops.int8_scaled_mm_with_quant(x, wi, si, None, torch.bfloat16, False))):
             ms = timed(fn, 10)
             emit(op=name, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
-                 roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma", engine="generic")
+                 roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
 
 
 def bench_attn():
