@@ -69,6 +69,34 @@ SGLK_DEV void stage_tile(unsigned char* lds, const KvSource& src, int p0, int nk
     }
 }
 
+// Split staging for software pipelining (issue the global loads of tile i+1 before computing tile i, write them to the
+// other LDS buffer afterwards).  Every thread resolves the rows of its own chunks (page lookups hit L1), so no
+// row-pointer table and no extra barrier is needed.  NCH = chunks per thread.
+template <int WIDTH, int THREADS>
+struct TileRegs {
+    static constexpr int CH = WIDTH / 8;
+    static constexpr int NCH = (kKeys * CH + THREADS - 1) / THREADS;
+    uint4 v[NCH];
+    SGLK_DEV void load(const KvSource& src, int p0, int nkeys) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * THREADS;
+            const int row = c / CH, ch = c - row * CH;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (c < kKeys * CH && row < nkeys) v[i] = *reinterpret_cast<const uint4*>(kv_row(src, p0 + row) + ch * 8);
+        }
+    }
+    SGLK_DEV void store(unsigned char* lds) const {
+        constexpr int MASK = Swz<CH>::mask;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * THREADS;
+            const int row = c / CH, ch = c - row * CH;
+            if (c < kKeys * CH) *reinterpret_cast<uint4*>(lds + row * (WIDTH * 2) + ((ch ^ (row & MASK)) << 4)) = v[i];
+        }
+    }
+};
+
 // Per-wave attention state and the per-tile update.  D, DV: head dims of K and V; QT: 16-column query tiles.
 template <int D, int DV, int QT>
 struct Core {
@@ -105,9 +133,15 @@ struct Core {
     template <bool V_ALIAS>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
                        float scale_log2e, float logit_cap, int lane) {
+        int lim_min = limit[0];
+#pragma unroll
+        for (int qt = 1; qt < QT; ++qt) lim_min = limit[qt] < lim_min ? limit[qt] : lim_min;
+        const bool masked = __any(key_base + kKeys > lim_min);
+        const bool capped = __builtin_amdgcn_readfirstlane(logit_cap > 0.f);
         constexpr int KMASK = Swz<KCH>::mask;
         constexpr int VW = V_ALIAS ? D : DV;                 // row width of the image V is read from
         constexpr int VMASK = V_ALIAS ? KMASK : Swz<VCH>::mask;
+        constexpr float kRescaleThr = 8.0f;                  // log2 units: P <= 2^8 before a rescale is forced
         const int r = lane & 15, g = lane >> 4;
         f32x4 s[QT][4];
 #pragma unroll
@@ -130,26 +164,48 @@ struct Core {
         bf16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+            // logits in log2 units; the soft-cap and the visibility mask are whole wave-uniform blocks (one scalar
+            // branch each), so full tiles below the causal diagonal run neither
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[qt][kt] *= scale_log2e;
+            if (capped) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // cap * tanh(x / cap) on the natural-log-scale logit
+                        const float x = s[qt][kt][j] * 0.6931471805599453f;
+                        s[qt][kt][j] = logit_cap * tanhf(x / logit_cap) * 1.4426950408889634f;
+                    }
+            }
+            if (masked) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = key_base + kt * 16 + g * 4 + j;
+                        s[qt][kt][j] = key < limit[qt] ? s[qt][kt][j] : -INFINITY;
+                    }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = s[qt][kt][j] * scale_log2e;          // logits in log2 units
-                    if (logit_cap > 0.f) {
-                        // cap * tanh(x / cap) on the natural-log-scale logit
-                        const float x = v * 0.6931471805599453f;
-                        v = logit_cap * tanhf(x / logit_cap) * 1.4426950408889634f;
-                    }
-                    const int key = key_base + kt * 16 + g * 4 + j;
-                    v = key < limit[qt] ? v : -INFINITY;
-                    s[qt][kt][j] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qt][kt][j]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m[qt], mx);
-            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qt] - m_new);
+            // Deferred rescale: keep the old reference maximum while the new one is at most 2^thr above it (P stays
+            // <= 2^thr, harmless in fp32 sums and in bf16 P); the branch is wave-uniform.  The first tile (m = -inf)
+            // and any larger jump take the exact path.
+            float m_new = m[qt];
+            if (__any(mx > m[qt] + kRescaleThr)) {
+                m_new = fmaxf(m[qt], mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qt] - m_new);
+                l[qt] *= alpha;
+#pragma unroll
+                for (int t = 0; t < VT; ++t) o[qt][t] *= alpha;
+                m[qt] = m_new;
+            }
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             float psum = 0.f;
             float p[4][4];
@@ -160,10 +216,7 @@ struct Core {
                     p[kt][j] = __builtin_amdgcn_exp2f(s[qt][kt][j] - m_use);   // exp2(-inf) = 0 for masked keys
                     psum += p[kt][j];
                 }
-            m[qt] = m_new;
-            l[qt] = l[qt] * alpha + psum;     // per-lane partial (this lane's keys); lane groups are summed at the end
-#pragma unroll
-            for (int t = 0; t < VT; ++t) o[qt][t] *= alpha;
+            l[qt] += psum;     // per-lane partial (this lane's keys); lane groups are summed at the end
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 u32x4 w;
@@ -230,13 +283,13 @@ struct ExtendParams {
 template <int D, int DV>
 __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParams p) {
     constexpr int QB = 128;   // queries per workgroup: 4 waves x 2 tiles x 16
-    __shared__ __attribute__((aligned(16))) unsigned char klds[kKeys * D * 2];
-    __shared__ __attribute__((aligned(16))) unsigned char vlds[kKeys * DV * 2];
-    __shared__ const unsigned short* rowptr[2][kKeys];
+    constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KB + VB)];   // two {K, V} tile buffers
 
     const int b = blockIdx.y, h = blockIdx.z;
     const int ext_len = p.b_seq_len_extend[b];
-    const int q0 = blockIdx.x * QB;
+    // heaviest query blocks (most keys under the causal mask) first
+    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;
     if (q0 >= ext_len) return;
     const int seq_len = (int)p.b_seq_len[b];
     const int prefix = seq_len - ext_len;
@@ -267,13 +320,31 @@ __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParam
     const int q_last = (q0 + QB < ext_len ? q0 + QB : ext_len);
     const int kv_end = prefix + q_last;       // the block's last query sees keys < prefix + q_last
     const float scale_log2e = p.sm_scale * 1.4426950408889634f;
-    for (int p0 = 0; p0 < kv_end; p0 += kKeys) {
-        const int nk = kv_end - p0 < kKeys ? kv_end - p0 : kKeys;
-        __syncthreads();   // previous tile fully consumed
-        stage_tile<D, 256>(klds, ks, p0, nk, rowptr[0]);
-        stage_tile<DV, 256>(vlds, vs, p0, nk, rowptr[1]);
+    const int ntiles = (kv_end + kKeys - 1) / kKeys;
+
+    // software pipeline: tile i+1 travels HBM -> registers while tile i is multiplied out of LDS
+    TileRegs<D, 256> kreg;
+    TileRegs<DV, 256> vreg;
+    auto nkeys = [&](int t) { const int r = kv_end - t * kKeys; return r < kKeys ? r : kKeys; };
+    kreg.load(ks, 0, nkeys(0));
+    vreg.load(vs, 0, nkeys(0));
+    kreg.store(lds);
+    vreg.store(lds + KB);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        unsigned char* cur = lds + (t & 1) * (KB + VB);
+        unsigned char* nxt = lds + ((t + 1) & 1) * (KB + VB);
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1));
+            vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1));
+        }
+        core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
+        if (more) {
+            kreg.store(nxt);      // `nxt` was last read in iteration t-1, which every wave left before this barrier's
+            vreg.store(nxt + KB); // predecessor; the barrier below publishes it for iteration t+1
+        }
         __syncthreads();
-        core.template tile<false>(klds, vlds, p0, limit, scale_log2e, p.logit_cap, lane);
     }
     // ---- normalise and store: lane (g, column) holds output dims 16t + 4g .. +3 of its query ----
     const int g4 = (lane >> 4) * 4;

@@ -18,6 +18,26 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Scratch for one call.  Reused per (device, stream): work on one stream is ordered, so the next call on the same
+    stream may overwrite it; other streams get their own buffer.  Grows monotonically."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(_ws_cache) > 64:
+            _ws_cache.clear()
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
 def _require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError(
@@ -149,9 +169,11 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
         hidden_states_c = hidden_states.contiguous()
     else:
         hidden_states_c = hidden_states
-    topk_weights = topk_weights.to(torch.float32).contiguous()
-    topk_ids = topk_ids.to(torch.int32).contiguous()
-    w1, w2 = w1.contiguous(), w2.contiguous()
+    topk_weights = _f32c(topk_weights)
+    if topk_ids.dtype != torch.int32 or not topk_ids.is_contiguous():
+        topk_ids = topk_ids.to(torch.int32).contiguous()
+    if not w1.is_contiguous() or not w2.is_contiguous():
+        w1, w2 = w1.contiguous(), w2.contiguous()
     bn, bk = 0, 0
     if int(method) == FP8_W8A16:
         if block_size is None or len(block_size) != 2:
@@ -160,14 +182,14 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
     if int(method) != UNQUANT:
         if w1_scale is None or w2_scale is None:
             raise RuntimeError("fused_experts: quantised modes need w1_scale and w2_scale")
-        w1_scale = w1_scale.to(torch.float32).contiguous()
-        w2_scale = w2_scale.to(torch.float32).contiguous()
+        w1_scale = _f32c(w1_scale)
+        w2_scale = _f32c(w2_scale)
 
     out = hidden_states_c if (inplace and hidden_states_c is hidden_states) else torch.empty_like(hidden_states_c)
     L = _lib.lib()
     wtype = _WTYPE[wdtype]
     ws_bytes = L.sglk_fused_experts_workspace_bytes(M, N, K, E, topk, wtype)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=hidden_states.device)
+    ws = _workspace(ws_bytes, hidden_states.device)
     args = _lib.FusedExpertsArgs(
         hidden=hidden_states_c.data_ptr(), hidden_stride=hidden_states_c.stride(0),
         out=out.data_ptr(), out_stride=out.stride(0),
