@@ -31,6 +31,12 @@ def build_all(force=False, verbose=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, "flags.txt")       # a change of compile flags (e.g. SGLK_DEV_ABLATE) rebuilds everything
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
+        with open(stamp, "w") as f:
+            f.write(flags_now)
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     jobs = []
     for s in srcs:

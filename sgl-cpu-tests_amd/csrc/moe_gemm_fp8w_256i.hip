@@ -28,7 +28,7 @@ namespace sglk {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-namespace g256x {
+namespace g256i {
 
 constexpr int kBM = 256;
 constexpr int kStageX = kBM * 128;        // 32 KiB
@@ -68,7 +68,7 @@ SGLK_DEV void split_scale(float s_in, float& pow2, float& mant) {
 }
 
 template <int MODE, int RESCALE>
-__global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGemmParams p) {
+__global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
 
     const int tid = threadIdx.x;
@@ -207,10 +207,11 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
 
     float pow2[2], pow2_next[2], mant[2], ratio[2];
 
-    // prologue: three stages in flight, wait for the first
+    // prologue: stages 0 and 1 complete and the first two pieces of stage 2 in flight (the rest of a stage's pieces are
+    // issued from inside the main loop, two stages ahead of their use)
     issue_stage(0, 0);
-    if (T > 1) issue_stage(1, 1);
-    if (T > 2) issue_piece(2, 2, 0);
+    issue_stage(1, 1);
+    if (T > 2) { issue_piece(2, 2, 0); issue_piece(2, 2, 1); }
     {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -234,83 +235,134 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
         ratio[rt] = 1.f;
     }
 
-    // A stage = 4 k-steps x 2 token-tile pairs = 8 groups of 4 MFMAs (2 row tiles x 2 token tiles).  The X fragments
-    // of the next group and the raw weight octets of the next k-step are read from LDS while the current group's
-    // MFMAs run.
-    bf16x8 xa[2], xb[2], wf[2];
+    // ---- main loop ----------------------------------------------------------------------------------------------------
+    // A stage = 4 k-steps of 8 MFMAs (2 weight row tiles x 4 token tiles).  One wave alone can keep the matrix pipe
+    // busy (tools/probe/mfma_peak.hip: 32.4 cycles per back-to-back mfma_32x32x16 = the pipe rate) but only if nothing
+    // else holds up its issue: every MFMA leaves a ~32-cycle shadow in which the same wave may issue other work for
+    // free, and whatever does not fit in the shadows is pipe idle time that the SIMD's second wave only partly fills
+    // (oldest-first arbitration).  So the feed of k-step c+1 -- 2 weight reads, 4 token reads, 8 conversions, the
+    // LDS-DMA pieces and, at K-block boundaries, the accumulator rescale -- is cut into eight slices and slice s is
+    // issued right behind MFMA s of k-step c.  The scheduling fences pin that order (left alone the scheduler
+    // clusters the MFMAs and sinks every LDS read to just in front of its use).
+    //   slot:      0      1      2      3        4            5            6         7
+    //   feed:    W rt0  W rt1  X tt0  X tt1+DMA  X tt2+2 cvt  X tt3+2 cvt  2 cvt     2 cvt + DMA
+    // Registers: converted weights wf[parity][rt], token fragments xf[parity][tt] (parity = k-step & 1), raw octets
+    // wraw[rt] of the k-step being converted.
+#define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
+    u32x4 wfw[2][2], xf[2][4];
     u32x2 wraw[2];
-    auto read_x = [&](bf16x8 (&xf)[2], int buf, int ks, int tp) {
-        if ((RESCALE & 16) && (ks | tp)) return;   // timing ablation only: one X read per stage
-        const unsigned char* sx = smem + buf * kStage;
-        xf[0] = *reinterpret_cast<const bf16x8*>(sx + xoff(2 * tp, ks));
-        xf[1] = *reinterpret_cast<const bf16x8*>(sx + xoff(2 * tp + 1, ks));
+    auto ld_w = [&](int rt, int fbuf, int ks) {
+        wraw[rt] = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt, ks));
     };
-    auto read_w = [&](int buf, int ks) {
-        const unsigned char* sw = smem + buf * kStage + kStageX;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) wraw[rt] = *reinterpret_cast<const u32x2*>(sw + woff(rt, ks));
+    auto ld_x = [&](int par, int tt, int fbuf, int ks) {
+        xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
-    auto cvt_w = [&]() {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            if (RESCALE & 8) {   // timing ablation only: no conversion
-                u32x4 t = {wraw[rt][0], wraw[rt][1], wraw[rt][0], wraw[rt][1]};
-                wf[rt] = __builtin_bit_cast(bf16x8, t);
-            } else {
-                wf[rt] = cvt8(wraw[rt][0], wraw[rt][1], pow2[rt]);
-            }
-        }
+    // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
+    auto cvt2 = [&](int par, int rt, int half, float sc2) {
+        const unsigned src = half ? wraw[rt][1] : wraw[rt][0];
+        wfw[par][rt][2 * half] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, false));
+        wfw[par][rt][2 * half + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, true));
     };
-    auto group = [&](const bf16x8 (&xf)[2], int tp) {
-        if (RESCALE & 2048) __builtin_amdgcn_s_setprio(1);   // per-group priority flips measured 3-4 % SLOWER here: off
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[rt][2 * tp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[rt], xf[j], acc[rt][2 * tp + j], 0, 0, 0);
-        if (RESCALE & 2048) __builtin_amdgcn_s_setprio(0);
+    auto mma = [&](int par, int s) {
+        const int rt = (s >> 1) & 1, tt = (s & 1) + 2 * (s >> 2);
+        acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfw[par][rt]),
+                                                              __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
     };
-
-    read_w(0, 0);
-    read_x(xa, 0, 0, 0);
-    if ((RESCALE & 512) && __builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);   // ablation: static priority for the younger half
-
-    int buf = 0;
-    const bool active = wm * 128 < rows;
-    auto idle_stage = [&](int t, bool wait6, bool dma2, int dma3, bool dma3_ok) {
-        int pbuf = buf - 1;
-        if (pbuf < 0) pbuf = kRing - 1;
-        if (dma2) {
+    auto rescale = [&](int a) {   // accumulator of MFMA slot a into units of the next K block's mantissa
+        const int rt = (a >> 1) & 1, tt = (a & 1) + 2 * (a >> 2);
+        // one plain v_mul_f32 per register: beside MFMAs a packed v_pk_mul_f32 costs the wave ~3x the issue time of the
+        // two scalar multiplies it replaces (MI355X_MICROARCH.md, cycle constants), and the vector form of this
+        // statement is always lowered to the packed instruction
 #pragma unroll
-            for (int i = 1; i < 6; ++i) issue_piece(t + 2, pbuf, i);
-        }
+        for (int i = 0; i < 16; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][i]) : "s"(ratio[rt]));
+    };
+    auto sync_point = [&](bool wait6) {
         if (wait6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (dma3 == 1 || (dma3 == 2 && dma3_ok)) issue_piece(t + 3, buf, 0);
-        buf = (buf + 1 == kRing) ? 0 : buf + 1;
     };
-#ifdef SGLK_DEV_ABLATE
-    unsigned long long dma_wait = 0, bar_wait = 0;
-#endif
-    // One 64-deep stage t; every flag is a literal at the call site (no control flow around the MFMA groups).
-    auto stage = [&](int t, bool first, bool closing, bool wait6, bool dma2, int dma3, bool dma3_ok, bool more) {
+
+    int buf = 0;
+    // k-step ks of the stage in ring slot `buf`; every flag is a literal at the call site.
+    //   fetch : read + convert the operands of the next k-step (same stage, or k-step 0 of the next stage when ks == 3)
+    //   sync  : ks == 3 only -- the next stage has landed and everybody is done with this stage's buffer (S_t)
+    //   dma_a / dma_b : LDS-DMA piece numbers issued in slots 3 / 7 (-1: none) for stage `dma_stage` into `dma_buf`
+    //   resc_lo / resc_hi : K-block boundary -- rescale accumulators 0..4 in slots 3..7 / accumulators 5..7 in slots 0..2
+    //   next_pow2 : the conversions of this k-step belong to the next K block
+    auto kstep = [&](int ks, bool fetch, bool sync, bool wait6, int dma_a, int dma_b, int dma_stage, int dma_buf,
+                     bool resc_lo, bool resc_hi, bool next_pow2) {
+        const int par = ks & 1, npar = par ^ 1;
         int nbuf = buf + 1;
         if (nbuf == kRing) nbuf = 0;
+        const int fbuf = (ks == 3) ? nbuf : buf;
+        const int fks = (ks + 1) & 3;
+        const float s0 = next_pow2 ? pow2_next[0] : pow2[0], s1 = next_pow2 ? pow2_next[1] : pow2[1];
+        // slot 0
+        mma(par, 0);
+        SGLK_FENCE();
+        if (sync) {
+            mma(par, 1);
+            SGLK_FENCE();
+            sync_point(wait6);
+            if (fetch) { ld_w(0, fbuf, fks); ld_w(1, fbuf, fks); }
+            if (resc_hi) { rescale(5); }
+            SGLK_FENCE();
+        } else {
+            if (fetch) ld_w(0, fbuf, fks);
+            if (resc_hi) rescale(5);
+            SGLK_FENCE();
+            // slot 1
+            mma(par, 1);
+            SGLK_FENCE();
+            if (fetch) ld_w(1, fbuf, fks);
+            if (resc_hi) rescale(6);
+            SGLK_FENCE();
+        }
+        // slot 2
+        mma(par, 2);
+        SGLK_FENCE();
+        if (fetch) ld_x(npar, 0, fbuf, fks);
+        if (resc_hi) rescale(7);
+        SGLK_FENCE();
+        // slot 3
+        mma(par, 3);
+        SGLK_FENCE();
+        if (fetch) ld_x(npar, 1, fbuf, fks);
+        if (dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
+        if (resc_lo) rescale(0);
+        SGLK_FENCE();
+        // slot 4
+        mma(par, 4);
+        SGLK_FENCE();
+        if (fetch) { ld_x(npar, 2, fbuf, fks); cvt2(npar, 0, 0, s0); }
+        if (resc_lo) rescale(1);
+        SGLK_FENCE();
+        // slot 5
+        mma(par, 5);
+        SGLK_FENCE();
+        if (fetch) { ld_x(npar, 3, fbuf, fks); cvt2(npar, 0, 1, s0); }
+        if (resc_lo) rescale(2);
+        SGLK_FENCE();
+        // slot 6
+        mma(par, 6);
+        SGLK_FENCE();
+        if (fetch) cvt2(npar, 1, 0, s1);
+        if (resc_lo) rescale(3);
+        SGLK_FENCE();
+        // slot 7
+        mma(par, 7);
+        SGLK_FENCE();
+        if (fetch) cvt2(npar, 1, 1, s1);
+        if (dma_b >= 0) issue_piece(dma_stage, dma_buf, dma_b);
+        if (resc_lo) rescale(4);
+        SGLK_FENCE();
+    };
+    // stage t.  first / closing: first / second stage of a 128-wide K block.  dma_mid: pieces 2..5 of stage t+2 go out in
+    // k-steps 0,1; dma_tail: pieces 0,1 of stage t+3 in k-step 3 (into this stage's own buffer, free after S_t).
+    auto stage = [&](int t, bool first, bool closing, bool has_next, bool wait6, bool dma_mid, bool dma_tail, bool boundary) {
         int pbuf = buf - 1;
         if (pbuf < 0) pbuf = kRing - 1;
-        if (first) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) pow2[rt] = pow2_next[rt];
-            // K block boundary: the whole accumulator into units of the new mantissa, in place
-            if (!(RESCALE & 4)) {
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[rt][tt] *= ratio[rt];
-            }
-        }
-        if (closing) {
+        if (closing && boundary) {
             const int kb = (t + 1) >> 1;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -320,80 +372,74 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
                 mant[rt] = nm;
             }
         }
-        // ks = 0
-        read_x(xb, buf, 0, 1);
-        cvt_w();
-        read_w(buf, 1);
-        group(xa, 0);
-        if (dma2) issue_piece(t + 2, pbuf, 1);
-        read_x(xa, buf, 1, 0);
-        group(xb, 1);
-        if (dma2) issue_piece(t + 2, pbuf, 2);
-        // ks = 1
-        read_x(xb, buf, 1, 1);
-        cvt_w();
-        read_w(buf, 2);
-        group(xa, 0);
-        if (dma2) issue_piece(t + 2, pbuf, 3);
-        read_x(xa, buf, 2, 0);
-        group(xb, 1);
-        if (dma2) issue_piece(t + 2, pbuf, 4);
-        // ks = 2
-        read_x(xb, buf, 2, 1);
-        cvt_w();
-        read_w(buf, 3);
-        group(xa, 0);
-        if (dma2) issue_piece(t + 2, pbuf, 5);
-        read_x(xa, buf, 3, 0);
-        group(xb, 1);
-        // ks = 3
-        read_x(xb, buf, 3, 1);
-        cvt_w();
-        group(xa, 0);
-        // sync point S_t in front of the last group (see the 16x16 kernel): stage t's buffer is free for the DMA of
-        // stage t+3, stage t+1 has landed, its first fragments are read now
-#ifdef SGLK_DEV_ABLATE
-        unsigned long long ta = 0, tb = 0;
-        if (p.dbg) ta = __builtin_amdgcn_s_memtime();
-#endif
-        if (wait6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef SGLK_DEV_ABLATE
-        if (p.dbg) tb = __builtin_amdgcn_s_memtime();
-#endif
-        if (RESCALE & 1024) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ablation: NO barrier (racy, timing only)
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#ifdef SGLK_DEV_ABLATE
-        if (p.dbg) { const unsigned long long tc = __builtin_amdgcn_s_memtime(); dma_wait += tb - ta; bar_wait += tc - tb; }
-#endif
-        if (dma3 == 1 || (dma3 == 2 && dma3_ok)) issue_piece(t + 3, buf, 0);
-        if (more) {
-            read_w(nbuf, 0);
-            read_x(xa, nbuf, 0, 0);
+        if (first) {   // conversions from here on belong to this K block (ratio == 1 and pow2_next == pow2 for t == 0)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) pow2[rt] = pow2_next[rt];
         }
-        group(xb, 1);
-        buf = nbuf;
+        kstep(0, true, false, false, dma_mid ? 2 : -1, dma_mid ? 3 : -1, t + 2, pbuf, false, first, false);
+        kstep(1, true, false, false, dma_mid ? 4 : -1, dma_mid ? 5 : -1, t + 2, pbuf, false, false, false);
+        kstep(2, true, false, false, -1, -1, 0, 0, false, false, false);
+        kstep(3, has_next, has_next, wait6, dma_tail ? 0 : -1, dma_tail ? 1 : -1, t + 3, buf, closing && boundary, false,
+              closing && boundary);
+        buf = (buf + 1 == kRing) ? 0 : buf + 1;
     };
+    // waves without rows (tail tiles): keep the DMA pieces and the sync points, skip the math
+    auto idle_stage = [&](int t, bool has_next, bool wait6, bool dma_mid, bool dma_tail) {
+        int pbuf = buf - 1;
+        if (pbuf < 0) pbuf = kRing - 1;
+        if (dma_mid) {
+#pragma unroll
+            for (int i = 2; i < 6; ++i) issue_piece(t + 2, pbuf, i);
+        }
+        if (has_next) sync_point(wait6);
+        if (dma_tail) { issue_piece(t + 3, buf, 0); issue_piece(t + 3, buf, 1); }
+        buf = (buf + 1 == kRing) ? 0 : buf + 1;
+    };
+
+    const bool active = wm * 128 < rows;
 #ifdef SGLK_DEV_ABLATE
-    // in-kernel clock of the main loop: shader cycles (s_memtime) over constant 100 MHz ticks (s_memrealtime)
     unsigned long long t0 = 0, r0 = 0;
     if (p.dbg && tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    // T = 2 * kblocks >= 4 stages.  Steady state while stage t+3 exists; the last two K blocks are peeled so that the
+    // DMA / wait flags stay literals.
     if (active) {
-        for (int kb = 0; kb + 1 < kblocks; ++kb) {
-            stage(2 * kb, true, false, true, true, 1, true, true);            // ratio == 1 for kb == 0
-            stage(2 * kb + 1, false, true, true, true, 2, kb + 2 < kblocks, true);
+        // operands of (stage 0, k-step 0)
+        ld_w(0, 0, 0);
+        ld_w(1, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) ld_x(0, tt, 0, 0);
+        cvt2(0, 0, 0, pow2[0]); cvt2(0, 0, 1, pow2[0]);
+        cvt2(0, 1, 0, pow2[1]); cvt2(0, 1, 1, pow2[1]);
+        SGLK_FENCE();
+        int t = 0;
+        for (; t + 4 < T; t += 2) {
+            stage(t, true, false, true, true, true, true, true);
+            stage(t + 1, false, true, true, true, true, true, true);
         }
-        stage(T - 2, true, false, false, false, 0, false, true);
-        stage(T - 1, false, false, false, false, 0, false, false);
+        // t == T - 4 (when T >= 4): stages T-4 .. T-1
+        if (t + 3 < T) {
+            stage(t, true, false, true, true, true, true, true);          // T-4: pieces 2..5 of T-2, pieces 0,1 of T-1
+            stage(t + 1, false, true, true, true, true, false, true);     // T-3: pieces 2..5 of T-1
+            t += 2;
+        }
+        stage(t, true, false, true, false, false, false, true);           // T-2: waits for all of T-1
+        stage(t + 1, false, true, false, false, false, false, false);     // T-1: nothing follows
     } else {
-        for (int kb = 0; kb + 1 < kblocks; ++kb) {
-            idle_stage(2 * kb, true, true, 1, true);
-            idle_stage(2 * kb + 1, true, true, 2, kb + 2 < kblocks);
+        int t = 0;
+        for (; t + 4 < T; t += 2) {
+            idle_stage(t, true, true, true, true);
+            idle_stage(t + 1, true, true, true, true);
         }
-        idle_stage(T - 2, false, false, 0, false);
-        idle_stage(T - 1, false, false, 0, false);
+        if (t + 3 < T) {
+            idle_stage(t, true, true, true, true);
+            idle_stage(t + 1, true, true, true, false);
+            t += 2;
+        }
+        idle_stage(t, true, false, false, false);
+        idle_stage(t + 1, false, false, false, false);
     }
+#undef SGLK_FENCE
 #ifdef SGLK_DEV_ABLATE
     if (p.dbg && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -404,10 +450,6 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
         p.dbg[32 * blockIdx.x + 20] = r1;
         p.dbg[32 * blockIdx.x + 22] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         p.dbg[32 * blockIdx.x + 23] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
-    }
-    if (p.dbg && lane == 0) {
-        p.dbg[32 * blockIdx.x + 2 + wave] = dma_wait;
-        p.dbg[32 * blockIdx.x + 10 + wave] = bar_wait;
     }
 #endif
 
@@ -522,24 +564,22 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
 #endif
 }
 
-}  // namespace g256x
+}  // namespace g256i
 
-int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
+int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
-    if ((p.C >> 7) > g256x::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
-    static const bool keep_x = getenv("SGLK_G256X") != nullptr;
-    if (!keep_x && (p.C >> 7) >= 2) return launch_moe_gemm_fp8w_256i(mode, p, max_mtiles, stream);
+    if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
     if (mode == MODE_PLAIN) {
-        hipLaunchKernelGGL((g256x::moe_gemm_fp8w_256x_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
         SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256x");
         return SGLK_OK;
     }
 #define SGLK_LAUNCH256X(R)                                                                                             \
     if (mode == MODE_GATE_UP)                                                                                          \
-        hipLaunchKernelGGL((g256x::moe_gemm_fp8w_256x_kernel<MODE_GATE_UP, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_GATE_UP, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
     else                                                                                                               \
-        hipLaunchKernelGGL((g256x::moe_gemm_fp8w_256x_kernel<MODE_DOWN, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p)
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_DOWN, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p)
 #ifdef SGLK_DEV_ABLATE   // developer-only timing ablations (wrong results by design)
     static const int abl = getenv("SGLK_RESCALE") ? atoi(getenv("SGLK_RESCALE")) : 0;
     switch (abl) {

@@ -32,6 +32,7 @@ struct MoeGemmParams {
     const uint16_t* addend;       // PLAIN: bf16 [rows][out columns] added as addend * addend_scale, or null
     int64_t addend_stride;
     float addend_scale;
+    int phases;                   // 256x kernel: start-up stagger of the first wave of workgroups (0/1 = none)
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
@@ -40,6 +41,9 @@ int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipSt
 int launch_moe_gemm_fp8w_256(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 // same tiling on mfma_f32_32x32x16_bf16 (moe_gemm_fp8w_256x.hip); needs block_n % 32 == 0
 int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+// same tile and ring, main loop issued MFMA by MFMA with the next k-step's feed in the shadows (moe_gemm_fp8w_256i.hip);
+// the 256x entry point forwards here unless SGLK_G256X is set
+int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
 constexpr int kGenericTileM = 64;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Developer tool (needs a SGLK_DEV_ABLATE build): per-workgroup timeline of the two grouped GEMMs of fused_experts at
+the bench shape -- prologue / main loop / epilogue durations and the gap between consecutive workgroups on a CU."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
+import torch
+import sgl_kernel  # noqa
+ops = torch.ops.sgl_kernel
+K, N, E, topk, M = 2048, 768, 128, 8, 16384
+g = torch.Generator(device="cuda").manual_seed(1)
+w1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+w1s = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3
+w2s = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
+a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+tw, ids = torch.topk(torch.softmax(torch.randn(M, E, device="cuda", generator=g), dim=-1), topk); ids = ids.to(torch.int32)
+dbg = torch.zeros(2 * 32 * 8192, dtype=torch.int64, device="cuda")
+os.environ["SGLK_DBG_PTR"] = hex(dbg.data_ptr())
+f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
+t0 = time.time()
+while time.time() - t0 < 2.0:
+    for _ in range(50): f()
+    torch.cuda.synchronize()
+dbg.zero_(); torch.cuda.synchronize()
+f(); torch.cuda.synchronize()
+both = dbg.cpu().view(2, -1, 32)
+for name, full in (("GEMM-1", both[0]), ("GEMM-2", both[1])):
+    full = full[full[:, 19] > 0].double()
+    entry, l0, l1, st, ack = full[:, 18], full[:, 19], full[:, 20], full[:, 21], full[:, 24]
+    us = lambda x: x / 100.0
+    print(f"{name}: {len(full)} workgroups; kernel span {us(ack.max() - entry.min()):.1f} us")
+    e1, e2, e3 = full[:, 25], full[:, 26], full[:, 27]
+    for lab, v in (("  epi: loop end -> barrier 1", e1 - l1), ("  epi: image written by wave 0", e2 - e1), ("  epi: barrier 2", e3 - e2),
+                   ("  epi: rows read + stores issued", st - e3), ("prologue (entry -> loop)", l0 - entry), ("main loop", l1 - l0), ("epilogue (loop end -> stores issued)", st - l1),
+                   ("store ack", ack - st), ("whole workgroup", ack - entry)):
+        print(f"   {lab:40s} median {us(v.median()):7.2f} us   p10 {us(v.quantile(0.1)):7.2f}   p90 {us(v.quantile(0.9)):7.2f}")
+    cu = (full[:, 23].long() << 32) | (full[:, 22].long() & 0xFF00)   # xcc | se/sh/cu bits of HW_ID
+    gaps, per_cu = [], []
+    for c in cu.unique():
+        sel = full[cu == c]
+        order = sel[:, 18].argsort()
+        sel = sel[order]
+        per_cu.append(len(sel))
+        if len(sel) > 1:
+            gaps.append(sel[1:, 18] - sel[:-1, 24])
+    gaps = torch.cat(gaps)
+    print(f"   CUs seen {len(per_cu)}, workgroups per CU min/max {min(per_cu)}/{max(per_cu)}; gap between consecutive workgroups on a CU: "
+          f"median {us(gaps.median()):.2f} us  p10 {us(gaps.quantile(0.1)):.2f}  p90 {us(gaps.quantile(0.9)):.2f}")
