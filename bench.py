@@ -191,7 +191,7 @@ def main():
                                    f"inplace=False, {LCLONES} rotating weight/input clones",
                        "tokens_per_gpu": M, "experts_per_gpu": E_local,
                        "parallelism": "single GPU" if world == 1 else f"ep{world} (RCCL all-to-all dispatch/combine)"},
-            "roofline": {"bound": "mfma", "kernel": "moe_gemm_fp8w_256_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
+            "roofline": {"bound": "mfma", "kernel": "g256i::moe_gemm_fp8w_256i_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
                          "achieved": round(gemm1_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm1_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "launches": int(calls.value), "avg_launch_ms": round(gemm1_ms, 4),

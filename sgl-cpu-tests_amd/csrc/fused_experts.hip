@@ -172,8 +172,6 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
 #ifdef SGLK_DEV_ABLATE
         if (const char* dp = getenv("SGLK_DBG_PTR")) g1.dbg = (unsigned long long*)strtoull(dp, nullptr, 16);
 #endif
-        static const int phases = getenv("SGLK_PHASES") ? atoi(getenv("SGLK_PHASES")) : 1;
-        g1.phases = phases;
         // 256-token tiles: 32x32x16 MFMA kernel unless the scale blocks are finer than its 32-row operand tiles
         static const bool force16 = getenv("SGLK_MFMA16") != nullptr;
         const bool use32 = !force16 && a->block_n % 32 == 0;
@@ -204,7 +202,6 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.out = ic2;
         g2.out_stride = K;
         g2.topk_weights = a->topk_weights;
-        g2.phases = phases;
 #ifdef SGLK_DEV_ABLATE
         if (g1.dbg) g2.dbg = g1.dbg + 32 * 8192;
 #endif

@@ -36,6 +36,47 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
     }
 }
 
+// topk known at compile time: all TOPK row loads of a chunk are issued back to back (no branch between them; slots of
+// masked experts are loaded too -- their rows exist in the workspace -- and dropped by a select, never added), so every
+// thread keeps TOPK 16-byte loads in flight instead of one.
+template <int TOPK>
+__global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* __restrict__ ic2,
+                                                                const int32_t* __restrict__ topk_ids,
+                                                                uint16_t* __restrict__ out, int64_t out_stride, int M,
+                                                                int K, int E) {
+    const int chunks_per_row = K >> 3;
+    const int64_t total = (int64_t)M * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks_per_row);
+        const int c = (int)(i - (int64_t)m * chunks_per_row);
+        const uint16_t* base = ic2 + (int64_t)m * TOPK * K + c * 8;
+        u32x4 v[TOPK];
+        int e[TOPK];
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)j * K));
+            e[j] = topk_ids[(int64_t)m * TOPK + j];
+        }
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) {
+            const bool ok = e[j] >= 0 && e[j] < E;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w = ok ? v[j][q] : 0u;
+                sum[2 * q] += __uint_as_float(w << 16);
+                sum[2 * q + 1] += __uint_as_float(w & 0xffff0000u);
+            }
+        }
+        u32x4 o;
+        o[0] = pack_bf16x2(sum[0], sum[1]);
+        o[1] = pack_bf16x2(sum[2], sum[3]);
+        o[2] = pack_bf16x2(sum[4], sum[5]);
+        o[3] = pack_bf16x2(sum[6], sum[7]);
+        *reinterpret_cast<u32x4*>(out + (int64_t)m * out_stride + c * 8) = o;
+    }
+}
+
 // any K / alignment: one element per thread (only the odd shapes of the generic path come here)
 __global__ __launch_bounds__(256) void moe_combine_scalar_kernel(const uint16_t* __restrict__ ic2,
                                                                  const int32_t* __restrict__ topk_ids,
@@ -68,8 +109,15 @@ int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* o
     const int64_t total = (int64_t)M * (K >> 3);
     int64_t blocks = ceil_div(total, 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ic2, topk_ids, out, out_stride,
-                       M, K, E, topk);
+    if (topk == 8)
+        hipLaunchKernelGGL(moe_combine_fixed_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, stream, ic2, topk_ids, out,
+                           out_stride, M, K, E);
+    else if (topk == 2)
+        hipLaunchKernelGGL(moe_combine_fixed_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, ic2, topk_ids, out,
+                           out_stride, M, K, E);
+    else
+        hipLaunchKernelGGL(moe_combine_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ic2, topk_ids, out, out_stride,
+                           M, K, E, topk);
     SGLK_CHECK_LAUNCH("moe_combine");
     return SGLK_OK;
 }

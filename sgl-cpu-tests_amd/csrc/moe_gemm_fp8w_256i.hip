@@ -75,36 +75,86 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
+
+    // ---- persistent workgroups: the launch has at most one workgroup per CU and each walks a strided list of tiles.
+    // Workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous tile range [xs, xs + xl) (equal
+    // shares, bijective for any count) so that one expert's weights and one m-tile's activations stay in one L2, and
+    // the workgroups of an XCD take consecutive tiles of that range in every round.
+    const int live = p.num_tiles[0] * p.n_tiles;
+    int xs, xl, nbx;
+    {
+        const int x = blockIdx.x & 7, q = live >> 3, r = live & 7;
+        xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        xl = q + (x < r ? 1 : 0);
+        nbx = ((int)gridDim.x - x + 7) >> 3;   // workgroups of this launch on XCD x
+    }
+    int jt = blockIdx.x >> 3;
+    if (jt >= xl) return;
+
+    // What a tile needs before its first LDS-DMA can go out sits behind two dependent round trips (tile table ->
+    // row table / scales).  For every tile but the first they are taken during the PREVIOUS tile: the table entry is
+    // loaded at its start, the dependent rows and scales just before its epilogue, so the next tile opens with
+    // nothing but the operand DMA to wait for.
+    struct Meta {
+        int4 ti;              // {expert, first position, rows, -}
+        int slots[4];         // GATE_UP: sorted_slot of the wave's four DMA row groups
+        int my_slot;          // DOWN: sorted_slot of tile row tid (tid < 256)
+        float sc_reg[2];      // scale-table entries tid, tid + 512
+    };
+    const int kblocks_ = p.C >> 7;
+    auto fetch_meta = [&](int Lq, Meta& m) {
+        const int mt = Lq / p.n_tiles, nt = Lq - mt * p.n_tiles;
+        const int e_ = __builtin_amdgcn_readfirstlane(m.ti.x), pos0_ = __builtin_amdgcn_readfirstlane(m.ti.y);
+        const int rows_ = __builtin_amdgcn_readfirstlane(m.ti.z);
+        const float* scale_e = p.w_scale + (int64_t)e_ * p.scale_rows * p.scale_cols;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * 512;
+            m.sc_reg[j] = 0.f;
+            if (i < 16 * kblocks_) {
+                const int piece = i / kblocks_, kb = i - piece * kblocks_;
+                int row16;
+                if (MODE == MODE_GATE_UP) row16 = (piece < 8) ? nt * 8 + piece : (p.n_half >> 4) + nt * 8 + (piece - 8);
+                else row16 = nt * 16 + piece;
+                m.sc_reg[j] = scale_e[((row16 * 16) / p.block_n) * p.scale_cols + kb];
+            }
+        }
+        m.my_slot = -1;
+        if (MODE == MODE_DOWN && tid < rows_) m.my_slot = p.sorted_slot[pos0_ + tid];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m.slots[i] = 0;
+            if (MODE == MODE_GATE_UP) {
+                const int r = (wave * 4 + i) * 8 + (lane >> 3);
+                m.slots[i] = p.sorted_slot[pos0_ + (r < rows_ ? r : 0)];
+            }
+        }
+    };
+    Meta cur, nxt;
+    cur.ti = p.tile_info[(xs + jt) / p.n_tiles];
+    fetch_meta(xs + jt, cur);
+    nxt = cur;
+
+    for (;;) {   // ---- one tile per iteration ---------------------------------------------------------------------
 #ifdef SGLK_DEV_ABLATE
     const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
-
-    // the grid is sized for the worst case; only the first num_tiles*n_tiles blocks have work.  The XCD remap is
-    // taken over THAT count, so every XCD gets an equal contiguous share of the real tiles.
-    const int live = p.num_tiles[0] * p.n_tiles;
-    if ((int)blockIdx.x >= live) return;
-    const int L = xcd_remap(blockIdx.x, live);
+    const int L = xs + jt;
+    const bool has_next_tile = jt + nbx < xl;
+    // next tile's table entry by SCALAR load (uniform address, constant address space): lands in SGPRs, costs no
+    // VGPR across the main loop and is consumed after it
+    if (has_next_tile)
+        nxt.ti = *reinterpret_cast<const __attribute__((address_space(4))) int4*>(
+            reinterpret_cast<uintptr_t>(p.tile_info + (L + nbx) / p.n_tiles));
     const int mtile = L / p.n_tiles;
     const int ntile = L - mtile * p.n_tiles;
-    const int4 ti = p.tile_info[mtile];
-    const int e = (RESCALE & 32) ? 0 : __builtin_amdgcn_readfirstlane(ti.x);   // bit 5: timing ablation, all-L2-hit operands
-    const int pos0 = (RESCALE & 32) ? 0 : __builtin_amdgcn_readfirstlane(ti.y);
-    const int rows = __builtin_amdgcn_readfirstlane(ti.z);
+    const int e = __builtin_amdgcn_readfirstlane(cur.ti.x);
+    const int pos0 = __builtin_amdgcn_readfirstlane(cur.ti.y);
+    const int rows = __builtin_amdgcn_readfirstlane(cur.ti.z);
 
     const int ctiles = p.C >> 6;
     const int kblocks = p.C >> 7;
     const int T = ctiles;
-
-    // Start-up stagger.  All tiles of a launch take the same time, so without it the 256 CUs run in lock-step: every
-    // CU reaches its epilogue together, the 32 MB of one round's output hit the L2 at once and drain at the HBM write
-    // rate while the memory system idles during the main loops.  The first workgroup of each CU waits a fraction
-    // (phase / phases) of a tile time once; later workgroups inherit the offset because they start when a CU frees up.
-    if (p.phases > 1 && blockIdx.x < 256) {
-        const int phase = (blockIdx.x >> 3) % p.phases;
-        const unsigned long long wait = (unsigned long long)phase * (unsigned)(T * 150 + 600) / (unsigned)p.phases;   // 100 MHz ticks
-        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
-    }
 
     // workgroup's 16 weight row-tiles: GATE_UP = 8 gate + 8 up, DOWN = 16 consecutive
     auto piece_row16 = [&](int piece) {
@@ -118,20 +168,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     float* sc = reinterpret_cast<float*>(smem + kScaleOff);            // sc[piece][kb]
     int* slot_tab = reinterpret_cast<int*>(smem + kRowTabOff);         // DOWN epilogue: output row (slot) ...
     float* tw_tab = reinterpret_cast<float*>(smem + kRowTabOff + kBM * 4);   // ... and routing weight per tile row
-    float sc_reg[2] = {0.f, 0.f};                                      // 16 * kblocks <= 1024 table entries
-    {
-        const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + j * 512;
-            if (i < 16 * kblocks) {
-                const int piece = i / kblocks, kb = i - piece * kblocks;
-                sc_reg[j] = scale_e[((piece_row16(piece) * 16) / p.block_n) * p.scale_cols + kb];
-            }
-        }
-    }
-    int my_slot = -1;
-    if (MODE == MODE_DOWN && tid < rows) my_slot = p.sorted_slot[pos0 + tid];
+    const float sc_reg[2] = {cur.sc_reg[0], cur.sc_reg[1]};           // 16 * kblocks <= 1024 table entries
+    const int my_slot = cur.my_slot;
 
     // ---- LDS-DMA sources: buffer descriptors (SGPRs) + ONE 32-bit per-lane offset per piece, fixed for the whole
     //      tile; the stage offset goes in the scalar soffset, so a stage costs 6 buffer_load...lds and no VALU ----
@@ -147,8 +185,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         const int rr = r < rows ? r : 0;
         int64_t xrow;
         if (MODE == MODE_GATE_UP) {
-            const int slot = p.sorted_slot[pos0 + rr];
-            xrow = (int64_t)(slot / p.topk) * p.x_stride;
+            xrow = (int64_t)(cur.slots[i] / p.topk) * p.x_stride;
         } else {
             xrow = (int64_t)(pos0 + rr) * p.x_stride;
         }
@@ -244,8 +281,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // LDS-DMA pieces and, at K-block boundaries, the accumulator rescale -- is cut into eight slices and slice s is
     // issued right behind MFMA s of k-step c.  The scheduling fences pin that order (left alone the scheduler
     // clusters the MFMAs and sinks every LDS read to just in front of its use).
-    //   slot:      0      1      2      3        4            5            6         7
-    //   feed:    W rt0  W rt1  X tt0  X tt1+DMA  X tt2+2 cvt  X tt3+2 cvt  2 cvt     2 cvt + DMA
+    //   slot:      0          1          2      3          4      5      6      7
+    //   feed:    W rt0+X tt0  W rt1+X tt1  X tt2  X tt3+DMA  2 cvt  2 cvt  2 cvt  2 cvt + DMA
     // Registers: converted weights wf[parity][rt], token fragments xf[parity][tt] (parity = k-step & 1), raw octets
     // wraw[rt] of the k-step being converted.
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -255,11 +292,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         wraw[rt] = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt, ks));
     };
     auto ld_x = [&](int par, int tt, int fbuf, int ks) {
+        if ((RESCALE & 16) && (ks | tt)) return;   // timing ablation: one X read per stage
         xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
     // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
     auto cvt2 = [&](int par, int rt, int half, float sc2) {
         const unsigned src = half ? wraw[rt][1] : wraw[rt][0];
+        if (RESCALE & 8) { wfw[par][rt][2 * half] = src; wfw[par][rt][2 * half + 1] = src; return; }   // timing ablation: no conversion
         wfw[par][rt][2 * half] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, false));
         wfw[par][rt][2 * half + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, true));
     };
@@ -269,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
                                                               __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
     };
     auto rescale = [&](int a) {   // accumulator of MFMA slot a into units of the next K block's mantissa
+        if (RESCALE & 4) return;   // timing ablation: no rescale
         const int rt = (a >> 1) & 1, tt = (a & 1) + 2 * (a >> 2);
         // one plain v_mul_f32 per register: beside MFMAs a packed v_pk_mul_f32 costs the wave ~3x the issue time of the
         // two scalar multiplies it replaces (MI355X_MICROARCH.md, cycle constants), and the vector form of this
@@ -279,7 +319,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     auto sync_point = [&](bool wait6) {
         if (wait6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (RESCALE & 1024) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // timing ablation: NO barrier (racy)
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
     int buf = 0;
@@ -304,43 +345,43 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             mma(par, 1);
             SGLK_FENCE();
             sync_point(wait6);
-            if (fetch) { ld_w(0, fbuf, fks); ld_w(1, fbuf, fks); }
+            if (fetch) { ld_w(0, fbuf, fks); ld_w(1, fbuf, fks); ld_x(npar, 0, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
             if (resc_hi) { rescale(5); }
             SGLK_FENCE();
         } else {
-            if (fetch) ld_w(0, fbuf, fks);
+            if (fetch) { ld_w(0, fbuf, fks); ld_x(npar, 0, fbuf, fks); }
             if (resc_hi) rescale(5);
             SGLK_FENCE();
             // slot 1
             mma(par, 1);
             SGLK_FENCE();
-            if (fetch) ld_w(1, fbuf, fks);
+            if (fetch) { ld_w(1, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
             if (resc_hi) rescale(6);
             SGLK_FENCE();
         }
         // slot 2
         mma(par, 2);
         SGLK_FENCE();
-        if (fetch) ld_x(npar, 0, fbuf, fks);
+        if (fetch) ld_x(npar, 2, fbuf, fks);
         if (resc_hi) rescale(7);
         SGLK_FENCE();
         // slot 3
         mma(par, 3);
         SGLK_FENCE();
-        if (fetch) ld_x(npar, 1, fbuf, fks);
+        if (fetch) ld_x(npar, 3, fbuf, fks);
         if (dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
         if (resc_lo) rescale(0);
         SGLK_FENCE();
         // slot 4
         mma(par, 4);
         SGLK_FENCE();
-        if (fetch) { ld_x(npar, 2, fbuf, fks); cvt2(npar, 0, 0, s0); }
+        if (fetch) cvt2(npar, 0, 0, s0);
         if (resc_lo) rescale(1);
         SGLK_FENCE();
         // slot 5
         mma(par, 5);
         SGLK_FENCE();
-        if (fetch) { ld_x(npar, 3, fbuf, fks); cvt2(npar, 0, 1, s0); }
+        if (fetch) cvt2(npar, 0, 1, s0);
         if (resc_lo) rescale(2);
         SGLK_FENCE();
         // slot 6
@@ -443,28 +484,35 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #ifdef SGLK_DEV_ABLATE
     if (p.dbg && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        p.dbg[32 * blockIdx.x] = t1 - t0;
-        p.dbg[32 * blockIdx.x + 1] = r1 - r0;
-        p.dbg[32 * blockIdx.x + 18] = rt_entry;   // absolute 100 MHz ticks: entry, loop start, loop end
-        p.dbg[32 * blockIdx.x + 19] = r0;
-        p.dbg[32 * blockIdx.x + 20] = r1;
-        p.dbg[32 * blockIdx.x + 22] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-        p.dbg[32 * blockIdx.x + 23] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+        p.dbg[32 * L] = t1 - t0;
+        p.dbg[32 * L + 1] = r1 - r0;
+        p.dbg[32 * L + 18] = rt_entry;   // absolute 100 MHz ticks: entry, loop start, loop end
+        p.dbg[32 * L + 19] = r0;
+        p.dbg[32 * L + 20] = r1;
+        p.dbg[32 * L + 22] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        p.dbg[32 * L + 23] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
     }
 #endif
+
+    if (has_next_tile) fetch_meta(L + nbx, nxt);   // dependent row / scale loads of the next tile fly during the epilogue
 
     // ---- epilogue: accumulator -> LDS image [token][column] (16-B chunks XOR-swizzled by token&15) -> rows ------
     // 32x32 accumulator: lane = token column (l&31); register i = weight row (i&3) + 8*(i>>2) + 4*(l>>5) of the tile
     __syncthreads();   // every wave is done reading the ring
+    // the epilogue's addressing is re-derived from an opaque copy of the thread id: hoisted out of the tile loop it
+    // would sit in ~30 VGPRs across the main loop, which has none to spare
+    int tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    const int r32e = tidv & 31, he = (tidv >> 5) & 1;
 #ifdef SGLK_DEV_ABLATE
-    if (p.dbg && tid == 0) p.dbg[32 * blockIdx.x + 25] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) p.dbg[32 * L + 25] = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int kCols = (MODE == MODE_GATE_UP) ? 128 : 256;   // output columns per workgroup
     constexpr int kRowB = kCols * 2;                            // bytes per token row in the image
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
         if (!active) break;
-        const int r = wm * 128 + tt * 32 + r32;
+        const int r = wm * 128 + tt * 32 + r32e;
         unsigned char* rowp = smem + r * kRowB;
         if (MODE == MODE_GATE_UP) {
 #pragma unroll
@@ -475,26 +523,9 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
                 uint2 v;
                 v.x = pack_bf16x2(silu_f32(g4[0]) * u4[0], silu_f32(g4[1]) * u4[1]);
                 v.y = pack_bf16x2(silu_f32(g4[2]) * u4[2], silu_f32(g4[3]) * u4[3]);
-                const int col = wn * 32 + rg * 8 + h * 4;            // 4 consecutive ic1 columns
+                const int col = wn * 32 + rg * 8 + he * 4;            // 4 consecutive ic1 columns
                 const int chunk = (col >> 3) ^ (r & 15);
                 *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
-            }
-        } else if (RESCALE & 4096) {   // variant: registers -> global directly (no LDS image, nothing to wait for)
-            if (r < rows) {
-                const int slot = slot_tab[r];
-                const float tw = tw_tab[r];
-                uint16_t* orow = p.out + (int64_t)slot * p.out_stride + ntile * kCols + wn * 64 + h * 4;
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const float sc_w = mant[rt] * tw;
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        uint2 v;
-                        v.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w, acc[rt][tt][rg * 4 + 1] * sc_w);
-                        v.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w, acc[rt][tt][rg * 4 + 3] * sc_w);
-                        *reinterpret_cast<uint2*>(orow + rt * 32 + rg * 8) = v;
-                    }
-                }
             }
         } else {
             float tw = 1.f;
@@ -508,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i] * sc_w;
                     if (MODE == MODE_PLAIN) {   // dense epilogue: + bias[col] + addend[row][col] * scale, in fp32
-                        const int gc = ntile * kCols + wn * 64 + rt * 32 + rg * 8 + h * 4;
+                        const int gc = ntile * kCols + wn * 64 + rt * 32 + rg * 8 + he * 4;
                         if (p.bias) {
                             const float4 b = *reinterpret_cast<const float4*>(p.bias + gc);
                             o4[0] += b.x; o4[1] += b.y; o4[2] += b.z; o4[3] += b.w;
@@ -524,26 +555,25 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
                     uint2 v;
                     v.x = pack_bf16x2(o4[0], o4[1]);
                     v.y = pack_bf16x2(o4[2], o4[3]);
-                    const int col = wn * 64 + rt * 32 + rg * 8 + h * 4;
+                    const int col = wn * 64 + rt * 32 + rg * 8 + he * 4;
                     const int chunk = (col >> 3) ^ (r & 15);
                     *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
                 }
             }
         }
     }
-    if (MODE == MODE_DOWN && (RESCALE & 4096)) return;
 #ifdef SGLK_DEV_ABLATE
-    if (p.dbg && tid == 0) p.dbg[32 * blockIdx.x + 26] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) p.dbg[32 * L + 26] = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
 #ifdef SGLK_DEV_ABLATE
-    if (p.dbg && tid == 0) p.dbg[32 * blockIdx.x + 27] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) p.dbg[32 * L + 27] = __builtin_amdgcn_s_memrealtime();
 #endif
     constexpr int kChunksPerRow = kRowB / 16;                   // 16 or 32
     constexpr int kIters = kBM * kChunksPerRow / 512;           // 8 or 16
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
-        const int idx = it * 512 + tid;
+        const int idx = it * 512 + tidv;
         const int r = idx / kChunksPerRow;
         const int pc = idx - r * kChunksPerRow;                 // physical chunk
         const int lc = pc ^ (r & 15);                           // logical chunk = 8 columns
@@ -557,18 +587,29 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     }
 #ifdef SGLK_DEV_ABLATE
     if (p.dbg && tid == 0) {
-        p.dbg[32 * blockIdx.x + 21] = __builtin_amdgcn_s_memrealtime();   // stores issued
+        p.dbg[32 * L + 21] = __builtin_amdgcn_s_memrealtime();   // stores issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p.dbg[32 * blockIdx.x + 24] = __builtin_amdgcn_s_memrealtime();   // stores acknowledged
+        p.dbg[32 * L + 24] = __builtin_amdgcn_s_memrealtime();   // stores acknowledged
     }
 #endif
+    if (!has_next_tile) break;
+    cur = nxt;
+    jt += nbx;
+    __syncthreads();   // the image and the row tables are dead: the next tile's DMA and tables may overwrite them
+    }   // tile loop
 }
 
 }  // namespace g256i
 
 int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
-    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (blocks > cus) blocks = cus;   // persistent: each workgroup walks its share of the live tiles
     if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
     if (mode == MODE_PLAIN) {
         hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
@@ -584,14 +625,12 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
     static const int abl = getenv("SGLK_RESCALE") ? atoi(getenv("SGLK_RESCALE")) : 0;
     switch (abl) {
         case 4: SGLK_LAUNCH256X(4); break;
-        case 28: SGLK_LAUNCH256X(28); break;
+        case 8: SGLK_LAUNCH256X(8); break;
+        case 16: SGLK_LAUNCH256X(16); break;
         case 64: SGLK_LAUNCH256X(64); break;
         case 92: SGLK_LAUNCH256X(92); break;
-        case 256: SGLK_LAUNCH256X(256); break;
-        case 1280: SGLK_LAUNCH256X(1280); break;
-        case 4096: SGLK_LAUNCH256X(4096); break;
-        case 2048: SGLK_LAUNCH256X(2048); break;
-        case 512: SGLK_LAUNCH256X(512); break;
+        case 1024: SGLK_LAUNCH256X(1024); break;
+        case 1116: SGLK_LAUNCH256X(1116); break;
         default: SGLK_LAUNCH256X(0); break;
     }
 #else

@@ -95,17 +95,6 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256x_kernel(const MoeGem
     const int kblocks = p.C >> 7;
     const int T = ctiles;
 
-    // Start-up stagger.  All tiles of a launch take the same time, so without it the 256 CUs run in lock-step: every
-    // CU reaches its epilogue together, the 32 MB of one round's output hit the L2 at once and drain at the HBM write
-    // rate while the memory system idles during the main loops.  The first workgroup of each CU waits a fraction
-    // (phase / phases) of a tile time once; later workgroups inherit the offset because they start when a CU frees up.
-    if (p.phases > 1 && blockIdx.x < 256) {
-        const int phase = (blockIdx.x >> 3) % p.phases;
-        const unsigned long long wait = (unsigned long long)phase * (unsigned)(T * 150 + 600) / (unsigned)p.phases;   // 100 MHz ticks
-        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-        while (__builtin_amdgcn_s_memrealtime() - t_in < wait) __builtin_amdgcn_s_sleep(32);
-    }
-
     // workgroup's 16 weight row-tiles: GATE_UP = 8 gate + 8 up, DOWN = 16 consecutive
     auto piece_row16 = [&](int piece) {
         if (MODE == MODE_GATE_UP) return (piece < 8) ? ntile * 8 + piece : (p.n_half >> 4) + ntile * 8 + (piece - 8);

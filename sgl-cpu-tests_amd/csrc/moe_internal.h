@@ -32,7 +32,6 @@ struct MoeGemmParams {
     const uint16_t* addend;       // PLAIN: bf16 [rows][out columns] added as addend * addend_scale, or null
     int64_t addend_stride;
     float addend_scale;
-    int phases;                   // 256x kernel: start-up stagger of the first wave of workgroups (0/1 = none)
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 
