@@ -98,8 +98,9 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     struct Meta {
         int4 ti;              // {expert, first position, rows, -}
         int slots[4];         // GATE_UP: sorted_slot of the wave's four DMA row groups
-        int my_slot;          // DOWN: sorted_slot of tile row tid (tid < 256)
-        float sc_reg[2];      // scale-table entries tid, tid + 512
+        int my_slot;          // DOWN: sorted_slot of tile row tid (tid < 256) ...
+        float tw;             // ... and its routing weight (third round trip: fetched after the epilogue's stores)
+        float sc_reg[2];      // scale-table entries sc[tid], sc[tid + 512]  (sc[piece * 64 + kb])
     };
     const int kblocks_ = p.C >> 7;
     auto fetch_meta = [&](int Lq, Meta& m) {
@@ -107,19 +108,24 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         const int e_ = __builtin_amdgcn_readfirstlane(m.ti.x), pos0_ = __builtin_amdgcn_readfirstlane(m.ti.y);
         const int rows_ = __builtin_amdgcn_readfirstlane(m.ti.z);
         const float* scale_e = p.w_scale + (int64_t)e_ * p.scale_rows * p.scale_cols;
+        const float inv_bn = 1.0f / (float)p.block_n;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int i = tid + j * 512;
+            const int i = tid + j * 512;                 // table entry sc[piece * 64 + kb]: no division by kblocks
+            const int piece = i >> 6, kb = i & (kMaxKBlocks - 1);
             m.sc_reg[j] = 0.f;
-            if (i < 16 * kblocks_) {
-                const int piece = i / kblocks_, kb = i - piece * kblocks_;
+            if (kb < kblocks_) {
                 int row16;
                 if (MODE == MODE_GATE_UP) row16 = (piece < 8) ? nt * 8 + piece : (p.n_half >> 4) + nt * 8 + (piece - 8);
                 else row16 = nt * 16 + piece;
-                m.sc_reg[j] = scale_e[((row16 * 16) / p.block_n) * p.scale_cols + kb];
+                // floor(row / block_n) through one float multiply: exact for rows < 2^20 (the +0.5 keeps the product
+                // at least 0.5 / block_n away from an integer, far more than the rounding error)
+                const int srow = (int)(((float)(row16 * 16) + 0.5f) * inv_bn);
+                m.sc_reg[j] = scale_e[srow * p.scale_cols + kb];
             }
         }
         m.my_slot = -1;
+        m.tw = 0.f;
         if (MODE == MODE_DOWN && tid < rows_) m.my_slot = p.sorted_slot[pos0_ + tid];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     Meta cur, nxt;
     cur.ti = p.tile_info[(xs + jt) / p.n_tiles];
     fetch_meta(xs + jt, cur);
+    if (MODE == MODE_DOWN && cur.my_slot >= 0) cur.tw = p.topk_weights[cur.my_slot];
     nxt = cur;
 
     for (;;) {   // ---- one tile per iteration ---------------------------------------------------------------------
@@ -143,9 +150,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     const bool has_next_tile = jt + nbx < xl;
     // next tile's table entry by SCALAR load (uniform address, constant address space): lands in SGPRs, costs no
     // VGPR across the main loop and is consumed after it
-    if (has_next_tile)
-        nxt.ti = *reinterpret_cast<const __attribute__((address_space(4))) int4*>(
+    if (has_next_tile) {
+        const __attribute__((address_space(4))) int* tp = reinterpret_cast<const __attribute__((address_space(4))) int*>(
             reinterpret_cast<uintptr_t>(p.tile_info + (L + nbx) / p.n_tiles));
+        nxt.ti.x = tp[0];
+        nxt.ti.y = tp[1];
+        nxt.ti.z = tp[2];
+    }
     const int mtile = L / p.n_tiles;
     const int ntile = L - mtile * p.n_tiles;
     const int e = __builtin_amdgcn_readfirstlane(cur.ti.x);
@@ -250,20 +261,16 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     issue_stage(1, 1);
     if (T > 2) { issue_piece(2, 2, 0); issue_piece(2, 2, 1); }
     {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + j * 512;
-            if (i < 16 * kblocks) {
-                const int piece = i / kblocks, kb = i - piece * kblocks;
-                sc[piece * kMaxKBlocks + kb] = sc_reg[j];
-            }
-        }
+        sc[tid] = sc_reg[0];
+        sc[tid + 512] = sc_reg[1];
         if (MODE == MODE_DOWN && tid < kBM) {
             slot_tab[tid] = my_slot;
-            tw_tab[tid] = my_slot >= 0 ? p.topk_weights[my_slot] : 0.f;
+            tw_tab[tid] = cur.tw;
         }
     }
-    __syncthreads();   // tables visible; drains the prologue DMA once
+    // stage 0 has landed (its six pieces are the oldest; stage 1 and the two pieces of stage 2 stay in flight), tables
+    // visible
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -593,6 +600,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     }
 #endif
     if (!has_next_tile) break;
+    if (MODE == MODE_DOWN && nxt.my_slot >= 0) nxt.tw = p.topk_weights[nxt.my_slot];
     cur = nxt;
     jt += nbx;
     __syncthreads();   // the image and the row tables are dead: the next tile's DMA and tables may overwrite them
@@ -609,7 +617,13 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    if (blocks > cus) blocks = cus;   // persistent: each workgroup walks its share of the live tiles
+    // Persistent launch (one workgroup per CU walking a strided share of the tiles, next tile's tables prefetched) vs one
+    // workgroup per tile (hardware dispatch balances tail tiles better).  Measured A/B on one box at the bench shape:
+    // persistent wins for the short reduction (K = 768: 0.464 vs 0.468 ms), loses for the long one (K = 2048: 0.778 vs
+    // 0.765 ms) where the prologue is a smaller share and the static split's imbalance costs more.
+    static const char* force = getenv("SGLK_PERSIST");   // "0" / "1" override for A/B runs
+    const bool persist = force ? force[0] == '1' : p.C <= 1024;
+    if (blocks > cus && persist) blocks = cus;
     if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
     if (mode == MODE_PLAIN) {
         hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
