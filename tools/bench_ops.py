@@ -2,7 +2,7 @@
 """Secondary measurements (not the driver's bench.py): the M sweep of fp8 fused_experts and the other
 operators of SURVEY.md §8 at the shapes the reference benches, each against the roofline that bounds it.
 
-    python tools/bench_ops.py [moe|gemm|attn|rows|all] > gpurun_out/bench_ops.json
+    python tools/bench_ops.py [moe|moe_literal|gemm|attn|rows|all] > gpurun_out/bench_ops.json
 
 Prints one JSON object per line.  HIP-event timing on the current stream, warm-up, rotating clones where the working
 set would otherwise sit in the 256 MiB Infinity Cache.
@@ -65,6 +65,41 @@ def bench_moe():
         emit(op="fused_experts_fp8", M=M, experts_touched=touched, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
              tokens_per_s=round(M / ms * 1e3), algorithmic_gb=round(byts / 1e9, 4), gbps=round(byts / ms / 1e6, 1),
              bound="mfma" if t_mfma > t_hbm else "hbm", roofline_frac=round(max(t_mfma, t_hbm) * 1e3 / ms, 4))
+
+
+def bench_moe_literal():
+    """The reference bench's literal shapes (bench_moe.py:144-145): M in {4, 3929}, N=384, K=7168, E=256, top-8, all
+    three weight types, prepacked weights, inplace=True like the reference loop."""
+    N, K, E, topk = 384, 7168, 256, 8
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w1f = torch.randn(E, 2 * N, K, device="cuda", generator=g)
+    w2f = torch.randn(E, K, N, device="cuda", generator=g)
+    packs = {}
+    packs["bf16"] = (ops.convert_weight_packed((w1f * 0.02).bfloat16()), ops.convert_weight_packed((w2f * 0.02).bfloat16()), None, None)
+    packs["fp8"] = (ops.convert_weight_packed((w1f * 400).clamp(-400, 400).to(torch.float8_e4m3fn)),
+                    ops.convert_weight_packed((w2f * 400).clamp(-400, 400).to(torch.float8_e4m3fn)),
+                    torch.rand(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-4,
+                    torch.rand(E, K // 128, N // 128, device="cuda", generator=g) * 1e-4)
+    packs["int8"] = (ops.convert_weight_packed((w1f * 40).clamp(-127, 127).round().to(torch.int8)),
+                     ops.convert_weight_packed((w2f * 40).clamp(-127, 127).round().to(torch.int8)),
+                     torch.rand(E, 2 * N, device="cuda", generator=g) * 1e-3, torch.rand(E, K, device="cuda", generator=g) * 1e-3)
+    del w1f, w2f
+    for M in (4, 3929):
+        a0 = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        score = torch.softmax(torch.randn(M, E, device="cuda", generator=g).bfloat16(), dim=-1, dtype=torch.float32)
+        tw, ids = torch.topk(score, topk)
+        ids = ids.to(torch.int32)
+        for kind, (w1, w2, s1, s2) in packs.items():
+            a = a0.clone()
+            if kind == "bf16":
+                fn = lambda i: ops.fused_experts_cpu(a, w1, w2, tw, ids, True, False, False, None, None, None, None, None, True)
+            elif kind == "int8":
+                fn = lambda i: ops.fused_experts_cpu(a, w1, w2, tw, ids, True, True, False, s1, s2, None, None, None, True)
+            else:
+                fn = lambda i: ops.fused_experts_cpu(a, w1, w2, tw, ids, True, False, True, s1, s2, [128, 128], None, None, True)
+            ms = timed(fn, 20)
+            emit(op="fused_experts_reference_shape", weights=kind, M=M, N=N, K=K, E=E, topk=topk, ms=round(ms, 4),
+                 tflops=round(M * topk * 6 * N * K / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3))
 
 
 def bench_gemm():
@@ -153,7 +188,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
