@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const uint16_t* __rest
     }
 }
 
-// topk known at compile time: all TOPK row loads of a chunk are issued back to back (no branch between them; slots of
-// masked experts are loaded too -- their rows exist in the workspace -- and dropped by a select, never added), so every
-// thread keeps TOPK 16-byte loads in flight instead of one.
+// topk known at compile time: all TOPK row loads of a chunk are issued back to back with no branch between them, so
+// every thread keeps TOPK 16-byte loads in flight instead of one.  A masked slot (expert id outside [0,E): the -1 of
+// expert parallelism, where most slots of a row are masked) re-reads the token's slot-0 address instead of its own
+// row -- a cache hit, no new HBM bytes -- and its value is dropped by a select, never added.
 template <int TOPK>
 __global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* __restrict__ ic2,
                                                                 const int32_t* __restrict__ topk_ids,
@@ -51,16 +52,19 @@ __global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* 
         const int c = (int)(i - (int64_t)m * chunks_per_row);
         const uint16_t* base = ic2 + (int64_t)m * TOPK * K + c * 8;
         u32x4 v[TOPK];
-        int e[TOPK];
+        bool valid[TOPK];
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) {
-            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)j * K));
-            e[j] = topk_ids[(int64_t)m * TOPK + j];
+            const int e = topk_ids[(int64_t)m * TOPK + j];
+            valid[j] = e >= 0 && e < E;
         }
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j)
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(valid[j] ? base + (int64_t)j * K : base));
         float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) {
-            const bool ok = e[j] >= 0 && e[j] < E;
+            const bool ok = valid[j];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned w = ok ? v[j][q] : 0u;

@@ -297,9 +297,14 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     u32x2 wraw[2];
     auto ld_w = [&](int rt, int fbuf, int ks) {
         wraw[rt] = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt, ks));
+        if (RESCALE & 128) {   // timing ablation: LDS traffic of a 2(n) x 4(m) wave layout (twice the W reads ...)
+            const u32x2 dup = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt ^ 1, ks));
+            asm volatile("" ::"v"(dup));
+        }
     };
     auto ld_x = [&](int par, int tt, int fbuf, int ks) {
         if ((RESCALE & 16) && (ks | tt)) return;   // timing ablation: one X read per stage
+        if ((RESCALE & 128) && tt >= 2) { xf[par][tt] = xf[par][tt - 2]; return; }   // ... and half the X reads
         xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
     // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
@@ -645,6 +650,7 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
         case 92: SGLK_LAUNCH256X(92); break;
         case 1024: SGLK_LAUNCH256X(1024); break;
         case 1116: SGLK_LAUNCH256X(1116); break;
+        case 128: SGLK_LAUNCH256X(128); break;
         default: SGLK_LAUNCH256X(0); break;
     }
 #else
