@@ -164,19 +164,20 @@ struct Core {
         bf16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            // logits in log2 units; the soft-cap and the visibility mask are whole wave-uniform blocks (one scalar
-            // branch each), so full tiles below the causal diagonal run neither
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] *= scale_log2e;
+            // s holds RAW q.k; the softmax scale rides in the exp2 argument (one v_fma per element instead of a
+            // multiply and a subtract).  The soft-cap and the visibility mask are whole wave-uniform blocks (one
+            // scalar branch each), so full tiles below the causal diagonal run neither.
+            float sc = scale_log2e;
             if (capped) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // cap * tanh(x / cap) on the natural-log-scale logit
-                        const float x = s[qt][kt][j] * 0.6931471805599453f;
+                        // cap * tanh(x / cap) on the natural-log-scale logit, stored in log2 units
+                        const float x = s[qt][kt][j] * scale_log2e * 0.6931471805599453f;
                         s[qt][kt][j] = logit_cap * tanhf(x / logit_cap) * 1.4426950408889634f;
                     }
+                sc = 1.f;
             }
             if (masked) {
 #pragma unroll
@@ -194,6 +195,7 @@ struct Core {
                 for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qt][kt][j]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx *= sc;                                        // log2 units (sc > 0)
             // Deferred rescale: keep the old reference maximum while the new one is at most 2^thr above it (P stays
             // <= 2^thr, harmless in fp32 sums and in bf16 P); the branch is wave-uniform.  The first tile (m = -inf)
             // and any larger jump take the exact path.
@@ -206,14 +208,14 @@ struct Core {
                 for (int t = 0; t < VT; ++t) o[qt][t] *= alpha;
                 m[qt] = m_new;
             }
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float neg_m = (m_new == -INFINITY) ? 0.f : -m_new;
             float psum = 0.f;
             float p[4][4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    p[kt][j] = __builtin_amdgcn_exp2f(s[qt][kt][j] - m_use);   // exp2(-inf) = 0 for masked keys
+                    p[kt][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][j], sc, neg_m));   // exp2(-inf) = 0 for masked keys
                     psum += p[kt][j];
                 }
             l[qt] += psum;     // per-lane partial (this lane's keys); lane groups are summed at the end
@@ -280,9 +282,12 @@ struct ExtendParams {
     float sm_scale, logit_cap;
 };
 
-template <int D, int DV>
-__global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParams p) {
-    constexpr int QB = 128;   // queries per workgroup: 4 waves x 2 tiles x 16
+template <int D, int DV, int QT>
+__global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendParams p) {
+    // queries per workgroup: 8 waves (two per SIMD: one wave's softmax beside the other's MFMAs) x QT tiles x 16
+    // (QT = 2 where the register budget of 256 per lane allows it)
+    constexpr int QB = 8 * QT * 16;
+    constexpr int WQ = QT * 16;   // queries per wave
     constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KB + VB)];   // two {K, V} tile buffers
 
@@ -299,12 +304,12 @@ __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParam
     const int kvh_buf = p.HBUF == p.HKV ? kvh : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    Core<D, DV, 2> core;
+    Core<D, DV, QT> core;
     core.init();
-    int limit[2];
+    int limit[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int qi = q0 + wave * 32 + qt * 16 + (lane & 15);
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qi = q0 + wave * WQ + qt * 16 + (lane & 15);
         const bool valid = qi < ext_len;
         core.load_q(qt, valid ? p.q + (int64_t)(ext_start + qi) * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
         limit[qt] = valid ? prefix + qi + 1 : 0;     // causal: keys up to and including the query's own position
@@ -323,8 +328,11 @@ __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParam
     const int ntiles = (kv_end + kKeys - 1) / kKeys;
 
     // software pipeline: tile i+1 travels HBM -> registers while tile i is multiplied out of LDS
-    TileRegs<D, 256> kreg;
-    TileRegs<DV, 256> vreg;
+    TileRegs<D, 512> kreg;
+    TileRegs<DV, 512> vreg;
+    // a wave's 32 queries see keys < wave_kv_end: later tiles of the workgroup's stream are fully masked for it
+    const int wave_q_last = (q0 + wave * WQ + WQ < ext_len) ? q0 + wave * WQ + WQ : ext_len;
+    const int wave_kv_end = prefix + wave_q_last;
     auto nkeys = [&](int t) { const int r = kv_end - t * kKeys; return r < kKeys ? r : kKeys; };
     kreg.load(ks, 0, nkeys(0));
     vreg.load(vs, 0, nkeys(0));
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParam
             kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1));
             vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1));
         }
-        core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
+        if (t * kKeys < wave_kv_end) core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
         if (more) {
             kreg.store(nxt);      // `nxt` was last read in iteration t-1, which every wave left before this barrier's
             vreg.store(nxt + KB); // predecessor; the barrier below publishes it for iteration t+1
@@ -349,9 +357,9 @@ __global__ __launch_bounds__(256) void extend_attention_kernel(const ExtendParam
     // ---- normalise and store: lane (g, column) holds output dims 16t + 4g .. +3 of its query ----
     const int g4 = (lane >> 4) * 4;
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const float lsum = core.column_sum(qt);
-        const int qi = q0 + wave * 32 + qt * 16 + (lane & 15);
+        const int qi = q0 + wave * WQ + qt * 16 + (lane & 15);
         if (qi >= ext_len) continue;
         const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
         unsigned short* orow = p.o + (int64_t)(ext_start + qi) * p.o_s0 + (int64_t)h * p.o_s1;
@@ -505,11 +513,13 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
     const int64_t strides[] = {p.q_s0, p.q_s1, p.ke_s0, p.ke_s1, p.ve_s0, p.ve_s1, p.kb_s0, p.kb_s1, p.vb_s0, p.vb_s1};
     for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "extend_attention: q/k/v strides must be multiples of 8 elements");
     SGLK_REQUIRE(p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0, SGLK_ERR_SHAPE, "extend_attention: o strides must be multiples of 4 elements");
-    const dim3 grid((unsigned)ceil_div(a->max_len_extend, 128), (unsigned)a->B, (unsigned)a->HQ), block(256);
+    const dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
 #define EXT_CASE(DD, DDV)                                                                              \
     if (a->D == DD && a->DV == DDV) {                                                                  \
-        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV>), grid, block, 0, s, p);                  \
+        constexpr int QT = DD > 128 ? 1 : 2;                                                           \
+        const dim3 grid((unsigned)ceil_div(a->max_len_extend, 8 * QT * 16), (unsigned)a->B, (unsigned)a->HQ); \
+        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT>), grid, block, 0, s, p);              \
         SGLK_CHECK_LAUNCH("extend_attention");                                                         \
         return SGLK_OK;                                                                                \
     }
