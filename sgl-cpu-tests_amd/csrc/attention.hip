@@ -52,6 +52,13 @@ SGLK_DEV const unsigned short* kv_row(const KvSource& s, int p) {
     }
     return s.ext + (int64_t)(p - s.n_paged) * s.ext_stride_tok;
 }
+// Every position is paged (decode).  Branch-free on purpose: a branch around the page lookup makes the compiler wait
+// for every lookup before the next one is issued, which serialises a tile's 4..18 row fetches per lane (measured:
+// 13.6 us per 64-key MLA tile instead of ~3).
+SGLK_DEV const unsigned short* kv_row_paged(const KvSource& s, int p) {
+    const int64_t tok = s.page_is64 ? reinterpret_cast<const int64_t*>(s.page)[p] : (int64_t)reinterpret_cast<const int*>(s.page)[p];
+    return s.buf + tok * s.buf_stride_tok;
+}
 
 // stage `nkeys` (<= 64) rows of WIDTH bf16 into the swizzled LDS image; missing rows are zero-filled
 template <int WIDTH, int THREADS>
@@ -78,12 +85,18 @@ struct TileRegs {
     static constexpr int NCH = (kKeys * CH + THREADS - 1) / THREADS;
     uint4 v[NCH];
     SGLK_DEV void load(const KvSource& src, int p0, int nkeys) {
+        // two passes: row pointers (page lookups) first, then the row loads back to back
+        const unsigned short* rp[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * THREADS;
             const int row = c / CH, ch = c - row * CH;
+            rp[i] = (c < kKeys * CH && row < nkeys) ? kv_row(src, p0 + row) + ch * 8 : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
             v[i] = make_uint4(0, 0, 0, 0);
-            if (c < kKeys * CH && row < nkeys) v[i] = *reinterpret_cast<const uint4*>(kv_row(src, p0 + row) + ch * 8);
+            if (rp[i]) v[i] = *reinterpret_cast<const uint4*>(rp[i]);
         }
     }
     SGLK_DEV void store(unsigned char* lds) const {
@@ -130,17 +143,19 @@ struct Core {
 
     // one 64-key tile.  key_base: stream position of the tile's first key; limit[qt]: the lane's column may see keys
     // with position < limit; V_ALIAS: V rows live in the K image (row width D), else in its own image (row width DV)
-    template <bool V_ALIAS>
+    // DV here is the width of the V slice this wave accumulates; dv0 = its first column inside the V image, whose rows
+    // are VROW elements wide (0 = DV, i.e. the wave owns the whole width)
+    template <bool V_ALIAS, int VROW = 0>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
-                       float scale_log2e, float logit_cap, int lane) {
+                       float scale_log2e, float logit_cap, int lane, int dv0 = 0) {
         int lim_min = limit[0];
 #pragma unroll
         for (int qt = 1; qt < QT; ++qt) lim_min = limit[qt] < lim_min ? limit[qt] : lim_min;
         const bool masked = __any(key_base + kKeys > lim_min);
         const bool capped = __builtin_amdgcn_readfirstlane(logit_cap > 0.f);
         constexpr int KMASK = Swz<KCH>::mask;
-        constexpr int VW = V_ALIAS ? D : DV;                 // row width of the image V is read from
-        constexpr int VMASK = V_ALIAS ? KMASK : Swz<VCH>::mask;
+        constexpr int VW = V_ALIAS ? D : (VROW ? VROW : DV);   // row width of the image V is read from
+        constexpr int VMASK = V_ALIAS ? KMASK : Swz<VW / 8>::mask;
         constexpr float kRescaleThr = 8.0f;                  // log2 units: P <= 2^8 before a rescale is forced
         const int r = lane & 15, g = lane >> 4;
         f32x4 s[QT][4];
@@ -237,7 +252,7 @@ struct Core {
             for (int ss = 0; ss < 2; ++ss) {
                 const int row0 = ss * 32 + g * 4 + q;
                 const int row1 = row0 + 16;
-                const int col = t * 16 + pp * 4;            // in elements; 4 elements = 8 bytes inside one 16-B chunk
+                const int col = dv0 + t * 16 + pp * 4;      // in elements; 4 elements = 8 bytes inside one 16-B chunk
                 const int ch = col >> 3, sub = (col & 7) * 2;
                 const unsigned char* a0 = vlds + row0 * (VW * 2) + ((ch ^ (row0 & VMASK)) << 4) + sub;
                 const unsigned char* a1 = vlds + row1 * (VW * 2) + ((ch ^ (row1 & VMASK)) << 4) + sub;
@@ -402,12 +417,56 @@ struct DecodeParams {
     float sm_scale, logit_cap;
 };
 
-template <int D, int DV, bool V_ALIAS>
+typedef const __attribute__((address_space(1))) void* dma_gptr_t;
+typedef __attribute__((address_space(3))) void* dma_lptr_t;
+
+// LDS-DMA staging of one 64-key tile (no registers, asynchronous): the image is written linearly, 1 KiB per wave
+// instruction, and the 16-byte-chunk swizzle is applied to the SOURCE address.  Rows past `nkeys` re-read the last valid
+// row (finite data: their probabilities are exactly 0, but 0 * garbage must not be NaN).  Returns nothing to wait on:
+// the caller counts the instructions (kDmaPerThread) in its s_waitcnt vmcnt.
+template <int WIDTH>
+struct TileDma {
+    static constexpr int CH = WIDTH / 8;
+    static constexpr int N = (kKeys * CH + 255) / 256;   // DMA instructions per wave per tile
+    static_assert((kKeys * CH) % 256 == 0, "the image must be a whole number of 4-wave DMA rounds (head dim % 32 == 0)");
+    SGLK_DEV static void issue(unsigned char* lds, const KvSource& src, int p0, int nkeys, int wave, int lane) {
+        constexpr int MASK = Swz<CH>::mask;
+        constexpr int HALF = (N + 1) / 2;
+        // two passes per half: all row lookups first (independent loads, one wait), then the DMA instructions
+#pragma unroll
+        for (int h0 = 0; h0 < N; h0 += HALF) {
+            const unsigned short* g[HALF];
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const int i = h0 + j;
+                if (i < N) {
+                    const int c = i * 256 + wave * 64 + lane;        // linear chunk of the image this lane fills
+                    const int row = c / CH, slot = c - row * CH;
+                    const int rr = row < nkeys ? row : nkeys - 1;
+                    g[j] = kv_row_paged(src, p0 + rr) + ((slot ^ (row & MASK)) << 3);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) {
+                const int i = h0 + j;
+                if (i < N)
+                    __builtin_amdgcn_global_load_lds((dma_gptr_t)g[j], (dma_lptr_t)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    }
+};
+
+// 4 waves = CT column tiles (16 q heads each) x NDV slices of the value width: every wave computes the logits of its
+// 16 heads against all 64 keys and accumulates DV / NDV output columns, so the accumulator of the widest case
+// (MLA, DV = 512, 22 heads -> CT = 2, NDV = 2) is 64 registers and nothing spills.  K/V tiles arrive by LDS-DMA, two
+// tiles deep when the images fit (tile t+1 flies while tile t is multiplied).
+template <int D, int DV, bool V_ALIAS, int NDV>
 __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodeParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-    unsigned char* klds = dyn_lds;
-    unsigned char* vlds = V_ALIAS ? dyn_lds : dyn_lds + kKeys * D * 2;
-    const unsigned short** rowptr = reinterpret_cast<const unsigned short**>(dyn_lds + kKeys * D * 2 + (V_ALIAS ? 0 : kKeys * DV * 2));
+    constexpr int KB = kKeys * D * 2, VB = V_ALIAS ? 0 : kKeys * DV * 2;
+    constexpr bool kDouble = 2 * (KB + VB) <= 150 * 1024;
+    constexpr int DVW = DV / NDV;
+    constexpr int kDma = TileDma<D>::N + (V_ALIAS ? 0 : TileDma<DV>::N);
 
     const int b = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int group = p.HQ / p.HKV;
@@ -415,13 +474,14 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
     const int per = (seq_len + p.splits - 1) / p.splits;
     const int k_begin = split * per;
     const int k_end = (k_begin + per < seq_len) ? k_begin + per : seq_len;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = wave * 16 + (lane & 15);            // q head inside the group handled by this lane's column
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ct = wave / NDV, dsl = wave - ct * NDV;   // column tile, value slice
+    const int col = ct * 16 + (lane & 15);              // q head inside the group handled by this lane's column
     const bool col_valid = col < group;
-    const bool wave_active = wave * 16 < group;
+    const bool wave_active = ct * 16 < group;
     const int h = kvh * group + col;
 
-    Core<D, DV, 1> core;
+    Core<D, DVW, 1> core;
     core.init();
     if (wave_active) core.load_q(0, col_valid ? p.q + (int64_t)b * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
     int limit[1] = {col_valid ? k_end : 0};
@@ -434,18 +494,35 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
     vs = ks;
     vs.buf = p.v_buf + (int64_t)kvh * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
     const float scale_log2e = p.sm_scale * 1.4426950408889634f;
-    for (int p0 = k_begin; p0 < k_end; p0 += kKeys) {
+
+    const int ntiles = (k_end - k_begin + kKeys - 1) / kKeys;
+    auto issue = [&](int t, unsigned char* buf) {
+        const int p0 = k_begin + t * kKeys;
         const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
-        __syncthreads();
-        // positions are absolute stream positions: stage_tile adds threadIdx to p0
-        stage_tile<D, 256>(klds, ks, p0, nk, rowptr);
-        if (!V_ALIAS) {
-            __syncthreads();   // rowptr is reused
-            stage_tile<DV, 256>(vlds, vs, p0, nk, rowptr);
+        TileDma<D>::issue(buf, ks, p0, nk, wave, lane);
+        if (!V_ALIAS) TileDma<DV>::issue(buf + KB, vs, p0, nk, wave, lane);
+    };
+    if (ntiles > 0) issue(0, dyn_lds);
+    for (int t = 0; t < ntiles; ++t) {
+        unsigned char* cur = dyn_lds + (kDouble ? (t & 1) * (KB + VB) : 0);
+        if (kDouble) {
+            // every wave has left tile t-1 (whose buffer tile t+1 overwrites) before anyone passes this barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < ntiles) issue(t + 1, dyn_lds + ((t + 1) & 1) * (KB + VB));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        __syncthreads();
-        if (wave_active) core.template tile<V_ALIAS>(klds, vlds, p0, limit, scale_log2e, p.logit_cap, lane);
+        if (wave_active)
+            core.template tile<V_ALIAS, DV>(cur, V_ALIAS ? cur : cur + KB, k_begin + t * kKeys, limit, scale_log2e, p.logit_cap,
+                                            lane, dsl * DVW);
+        if (!kDouble) {
+            __syncthreads();                     // the single buffer is free again
+            if (t + 1 < ntiles) issue(t + 1, dyn_lds);
+        }
     }
+    (void)kDma;
     if (!wave_active) return;
     const float lsum = core.column_sum(0);
     if (!col_valid) return;
@@ -453,13 +530,13 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
     const int g4 = (lane >> 4) * 4;
 #pragma unroll
-    for (int t = 0; t < DV / 16; ++t) {
+    for (int t = 0; t < DVW / 16; ++t) {
         const f32x4 v = core.o[0][t] * inv;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[t * 16 + g4 + j] = v[j];
+        for (int j = 0; j < 4; ++j) dst[dsl * DVW + t * 16 + g4 + j] = v[j];
     }
     // log-sum-exp of the split in log2 units (m is in log2 units); -inf marks an empty split
-    if ((lane >> 4) == 0) dst[DV] = lsum > 0.f ? core.m[0] + __builtin_amdgcn_logf(lsum) : -INFINITY;
+    if (dsl == 0 && (lane >> 4) == 0) dst[DV] = lsum > 0.f ? core.m[0] + __builtin_amdgcn_logf(lsum) : -INFINITY;
 }
 
 __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ logits, unsigned short* __restrict__ o,
@@ -561,16 +638,24 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
                        a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
     const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)a->splits), block(256);
+    const int group = a->HQ / a->HKV;
+#define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
+    {                                                                                                              \
+        constexpr size_t kb = (size_t)kKeys * DD * 2, vb = (AL) ? 0 : (size_t)kKeys * DDV * 2;                     \
+        constexpr size_t lds = (2 * (kb + vb) <= 150 * 1024) ? 2 * (kb + vb) : (kb + vb);                          \
+        hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, AL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND>), grid, block, lds, s, p);                    \
+    }
 #define DEC_CASE(DD, DDV)                                                                                          \
     if (a->D == DD && a->DV == DDV) {                                                                              \
         if (alias) {                                                                                               \
-            const size_t lds = (size_t)kKeys * DD * 2 + kKeys * 8;                                                 \
-            hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, true>), grid, block, lds, s, p);                  \
+            if (group <= 16) DEC_LAUNCH(DD, DDV, true, 4)                                                          \
+            else if (group <= 32) DEC_LAUNCH(DD, DDV, true, 2)                                                     \
+            else DEC_LAUNCH(DD, DDV, true, 1)                                                                      \
         } else {                                                                                                   \
-            const size_t lds = (size_t)kKeys * (DD + DDV) * 2 + kKeys * 8;                                         \
-            hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, false>), grid, block, lds, s, p);                 \
+            if (group <= 16) DEC_LAUNCH(DD, DDV, false, 4)                                                         \
+            else if (group <= 32) DEC_LAUNCH(DD, DDV, false, 2)                                                    \
+            else DEC_LAUNCH(DD, DDV, false, 1)                                                                     \
         }                                                                                                          \
         SGLK_CHECK_LAUNCH("decode_attention");                                                                     \
         hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)a->B, (unsigned)a->HQ), dim3(256), 0, s, a->attn_logits,    \
@@ -583,5 +668,6 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     DEC_CASE(192, 128)
     DEC_CASE(64, 64)
 #undef DEC_CASE
+#undef DEC_LAUNCH
     SGLK_FAIL(SGLK_ERR_SHAPE, "decode_attention: head dims D=%d DV=%d not built (have 576/512, 128/128, 192/128, 64/64)", a->D, a->DV);
 }
