@@ -47,7 +47,18 @@ __global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* 
                                                                 int K, int E) {
     const int chunks_per_row = K >> 3;
     const int64_t total = (int64_t)M * chunks_per_row;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    // the expert ids of item i+stride are fetched while item i's rows are in flight, so the id -> row-address
+    // dependency is never exposed
+    int e_cur[TOPK], e_nxt[TOPK];
+    {
+        const int m0 = (int)(i / chunks_per_row);
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) e_cur[j] = topk_ids[(int64_t)m0 * TOPK + j];
+    }
+    for (; i < total; i += stride) {
         const int m = (int)(i / chunks_per_row);
         const int c = (int)(i - (int64_t)m * chunks_per_row);
         const uint16_t* base = ic2 + (int64_t)m * TOPK * K + c * 8;
@@ -55,12 +66,19 @@ __global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* 
         bool valid[TOPK];
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) {
-            const int e = topk_ids[(int64_t)m * TOPK + j];
-            valid[j] = e >= 0 && e < E;
+            valid[j] = e_cur[j] >= 0 && e_cur[j] < E;
+            // row index picked by a select the optimiser cannot turn back into a branch around the load (it does, and
+            // then waits for each load before the next branch)
+            int jj = valid[j] ? j : 0;
+            asm volatile("" : "+v"(jj));
+            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)jj * K));
         }
+        {
+            const int64_t in = i + stride < total ? i + stride : i;
+            const int mn = (int)(in / chunks_per_row);
 #pragma unroll
-        for (int j = 0; j < TOPK; ++j)
-            v[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(valid[j] ? base + (int64_t)j * K : base));
+            for (int j = 0; j < TOPK; ++j) e_nxt[j] = topk_ids[(int64_t)mn * TOPK + j];
+        }
         float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TOPK; ++j) {
@@ -78,6 +96,8 @@ __global__ __launch_bounds__(256) void moe_combine_fixed_kernel(const uint16_t* 
         o[2] = pack_bf16x2(sum[4], sum[5]);
         o[3] = pack_bf16x2(sum[6], sum[7]);
         *reinterpret_cast<u32x4*>(out + (int64_t)m * out_stride + c * 8) = o;
+#pragma unroll
+        for (int j = 0; j < TOPK; ++j) e_cur[j] = e_nxt[j];
     }
 }
 

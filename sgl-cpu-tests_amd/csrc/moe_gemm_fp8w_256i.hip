@@ -67,14 +67,19 @@ SGLK_DEV void split_scale(float s_in, float& pow2, float& mant) {
     mant = tiny ? 1.f : (special ? s : __uint_as_float((u & 0x807fffffu) | 0x3f800000u));
 }
 
-template <int MODE, int RESCALE>
+// NRT x NTT = the wave's tile in 32-row weight tiles x 32-token tiles (8 accumulator tiles either way):
+//   NRT = 2: waves 4(n) x 2(m), 64 weight rows x 128 tokens  (LDS reads per stage: X 128 KiB + W 32 KiB)
+//   NRT = 4: waves 2(n) x 4(m), 128 weight rows x 64 tokens  (X 64 KiB + W 64 KiB: 20 % fewer LDS bytes -- the fp8
+//            weight fragments are half the size of the bf16 token fragments -- for twice the conversions)
+template <int MODE, int RESCALE, int NRT>
 __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGemmParams p) {
+    constexpr int NTT = 8 / NRT;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;
+    const int wn = NRT == 2 ? (wave & 3) : (wave & 1), wm = NRT == 2 ? (wave >> 2) : (wave >> 1);
 
     // ---- persistent workgroups: the launch has at most one workgroup per CU and each walks a strided list of tiles.
     // Workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous tile range [xs, xs + xl) (equal
@@ -228,32 +233,33 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // Weight row tile rt (32 rows) = two packed 16-row pieces; octet o = 2*ks + h of row r sits in piece (r>>4) at lane
     // slot ((o&3)*16 + (r&15)), byte (o>>2)*8 (pack.hip order) -> one ds_read_b64 per (rt, ks).
     const int h = lane >> 5, r32 = lane & 31;
-    int wbase[2];      // byte offset of (rt, lane) inside a W stage, without the k-step term
-    int wpiece0[2];    // first piece of the row tile (for the scale table)
+    int wbase[NRT];      // byte offset of (rt, lane) inside a W stage, without the k-step term
+    int wpiece0[NRT];    // first piece of the row tile (for the scale table)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        if (MODE == MODE_GATE_UP) wpiece0[rt] = (rt == 0) ? wn * 2 : 8 + wn * 2;
-        else wpiece0[rt] = wn * 4 + rt * 2;
+    for (int rt = 0; rt < NRT; ++rt) {
+        // GATE_UP: the first NRT/2 row tiles are gate rows, the rest the matching up rows (same output columns)
+        if (MODE == MODE_GATE_UP) wpiece0[rt] = (rt < NRT / 2) ? wn * NRT + rt * 2 : 8 + wn * NRT + (rt - NRT / 2) * 2;
+        else wpiece0[rt] = wn * NRT * 2 + rt * 2;
         wbase[rt] = (wpiece0[rt] + (r32 >> 4)) * 1024 + (r32 & 15) * 16;
     }
     // k-step ks: octet o = 2ks + h -> slot group (o&3), half (o>>2)
     auto woff = [&](int rt, int ks) { return wbase[rt] + (((2 * ks + h) & 3) * 16) * 16 + ((2 * ks + h) >> 2) * 8; };
-    // token tile tt (32 tokens): row = wm*128 + tt*32 + r32, chunk 2ks + h, swizzled by (row>>1)&7
-    const int xrow0 = wm * 128 + r32;
+    // token tile tt (32 tokens): row = wm*NTT*32 + tt*32 + r32, chunk 2ks + h, swizzled by (row>>1)&7
+    const int xrow0 = wm * (NTT * 32) + r32;
     auto xoff = [&](int tt, int ks) {
         const int row = xrow0 + tt * 32;
         return row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[NRT][NTT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0.f;
 
-    float pow2[2], pow2_next[2], mant[2], ratio[2];
+    float pow2[NRT], pow2_next[NRT], mant[NRT], ratio[NRT];
 
     // prologue: stages 0 and 1 complete and the first two pieces of stage 2 in flight (the rest of a stage's pieces are
     // issued from inside the main loop, two stages ahead of their use)
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < NRT; ++rt) {
         split_scale(sc[wpiece0[rt] * kMaxKBlocks], pow2[rt], mant[rt]);
         pow2_next[rt] = pow2[rt];
         ratio[rt] = 1.f;
@@ -293,18 +299,16 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // Registers: converted weights wf[parity][rt], token fragments xf[parity][tt] (parity = k-step & 1), raw octets
     // wraw[rt] of the k-step being converted.
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
-    u32x4 wfw[2][2], xf[2][4];
-    u32x2 wraw[2];
+    u32x4 wfw[2][NRT], xf[2][NTT];
+    u32x2 wraw[NRT];
+    // MFMA slot s of a k-step -> (row tile, token tile); consecutive slots alternate accumulators
+    auto slot_rt = [&](int s2) { return NRT == 2 ? (s2 >> 1) & 1 : s2 >> 1; };
+    auto slot_tt = [&](int s2) { return NRT == 2 ? (s2 & 1) + 2 * (s2 >> 2) : s2 & 1; };
     auto ld_w = [&](int rt, int fbuf, int ks) {
         wraw[rt] = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt, ks));
-        if (RESCALE & 128) {   // timing ablation: LDS traffic of a 2(n) x 4(m) wave layout (twice the W reads ...)
-            const u32x2 dup = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt ^ 1, ks));
-            asm volatile("" ::"v"(dup));
-        }
     };
     auto ld_x = [&](int par, int tt, int fbuf, int ks) {
         if ((RESCALE & 16) && (ks | tt)) return;   // timing ablation: one X read per stage
-        if ((RESCALE & 128) && tt >= 2) { xf[par][tt] = xf[par][tt - 2]; return; }   // ... and half the X reads
         xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
     // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
@@ -314,14 +318,14 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         wfw[par][rt][2 * half] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, false));
         wfw[par][rt][2 * half + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, true));
     };
-    auto mma = [&](int par, int s) {
-        const int rt = (s >> 1) & 1, tt = (s & 1) + 2 * (s >> 2);
+    auto mma = [&](int par, int s2) {
+        const int rt = slot_rt(s2), tt = slot_tt(s2);
         acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfw[par][rt]),
                                                               __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
     };
     auto rescale = [&](int a) {   // accumulator of MFMA slot a into units of the next K block's mantissa
         if (RESCALE & 4) return;   // timing ablation: no rescale
-        const int rt = (a >> 1) & 1, tt = (a & 1) + 2 * (a >> 2);
+        const int rt = slot_rt(a), tt = slot_tt(a);
         // one plain v_mul_f32 per register: beside MFMAs a packed v_pk_mul_f32 costs the wave ~3x the issue time of the
         // two scalar multiplies it replaces (MI355X_MICROARCH.md, cycle constants), and the vector form of this
         // statement is always lowered to the packed instruction
@@ -349,7 +353,26 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         if (nbuf == kRing) nbuf = 0;
         const int fbuf = (ks == 3) ? nbuf : buf;
         const int fks = (ks + 1) & 3;
-        const float s0 = next_pow2 ? pow2_next[0] : pow2[0], s1 = next_pow2 ? pow2_next[1] : pow2[1];
+        // feed slices of the NEXT k-step (fks of fbuf), by slot:
+        //   NRT = 2:  0: W0+X0   1: W1+X1   2: X2   3: X3        4..7: one half row tile converted per slot
+        //   NRT = 4:  0: W0+X0   1: W1+X1   2: W2   3: W3        4..7: one whole row tile converted per slot
+        auto feed_reads = [&](int s2) {
+            if (!fetch) return;
+            if (s2 < NRT) ld_w(s2, fbuf, fks);
+            if (s2 < NTT) ld_x(npar, s2, fbuf, fks);
+        };
+        auto feed_cvt = [&](int s2) {   // s2 in 4..7
+            if (!fetch) return;
+            if (NRT == 2) {
+                const int rt = (s2 - 4) >> 1, half = (s2 - 4) & 1;
+                cvt2(npar, rt, half, next_pow2 ? pow2_next[rt] : pow2[rt]);
+            } else {
+                const int rt = s2 - 4;
+                const float sc2 = next_pow2 ? pow2_next[rt] : pow2[rt];
+                cvt2(npar, rt, 0, sc2);
+                cvt2(npar, rt, 1, sc2);
+            }
+        };
         // slot 0
         mma(par, 0);
         SGLK_FENCE();
@@ -357,58 +380,44 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             mma(par, 1);
             SGLK_FENCE();
             sync_point(wait6);
-            if (fetch) { ld_w(0, fbuf, fks); ld_w(1, fbuf, fks); ld_x(npar, 0, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            feed_reads(0);
+            feed_reads(1);
             if (resc_hi) { rescale(5); }
             SGLK_FENCE();
         } else {
-            if (fetch) { ld_w(0, fbuf, fks); ld_x(npar, 0, fbuf, fks); }
+            feed_reads(0);
             if (resc_hi) rescale(5);
             SGLK_FENCE();
             // slot 1
             mma(par, 1);
             SGLK_FENCE();
-            if (fetch) { ld_w(1, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            feed_reads(1);
             if (resc_hi) rescale(6);
             SGLK_FENCE();
         }
         // slot 2
         mma(par, 2);
         SGLK_FENCE();
-        if (fetch) ld_x(npar, 2, fbuf, fks);
+        feed_reads(2);
         if (resc_hi) rescale(7);
         SGLK_FENCE();
         // slot 3
         mma(par, 3);
         SGLK_FENCE();
-        if (fetch) ld_x(npar, 3, fbuf, fks);
+        feed_reads(3);
         if (dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
         if (resc_lo) rescale(0);
         SGLK_FENCE();
-        // slot 4
-        mma(par, 4);
-        SGLK_FENCE();
-        if (fetch) cvt2(npar, 0, 0, s0);
-        if (resc_lo) rescale(1);
-        SGLK_FENCE();
-        // slot 5
-        mma(par, 5);
-        SGLK_FENCE();
-        if (fetch) cvt2(npar, 0, 1, s0);
-        if (resc_lo) rescale(2);
-        SGLK_FENCE();
-        // slot 6
-        mma(par, 6);
-        SGLK_FENCE();
-        if (fetch) cvt2(npar, 1, 0, s1);
-        if (resc_lo) rescale(3);
-        SGLK_FENCE();
-        // slot 7
-        mma(par, 7);
-        SGLK_FENCE();
-        if (fetch) cvt2(npar, 1, 1, s1);
-        if (dma_b >= 0) issue_piece(dma_stage, dma_buf, dma_b);
-        if (resc_lo) rescale(4);
-        SGLK_FENCE();
+        // slots 4..7
+#pragma unroll
+        for (int s2 = 4; s2 < 8; ++s2) {
+            mma(par, s2);
+            SGLK_FENCE();
+            feed_cvt(s2);
+            if (s2 == 7 && dma_b >= 0) issue_piece(dma_stage, dma_buf, dma_b);
+            if (resc_lo) rescale(s2 - 3);
+            SGLK_FENCE();
+        }
     };
     // stage t.  first / closing: first / second stage of a 128-wide K block.  dma_mid: pieces 2..5 of stage t+2 go out in
     // k-steps 0,1; dma_tail: pieces 0,1 of stage t+3 in k-step 3 (into this stage's own buffer, free after S_t).
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         if (closing && boundary) {
             const int kb = (t + 1) >> 1;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < NRT; ++rt) {
                 float nm;
                 split_scale(sc[wpiece0[rt] * kMaxKBlocks + kb], pow2_next[rt], nm);
                 ratio[rt] = uniform_f32(mant[rt] * __builtin_amdgcn_rcpf(nm));
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         }
         if (first) {   // conversions from here on belong to this K block (ratio == 1 and pow2_next == pow2 for t == 0)
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) pow2[rt] = pow2_next[rt];
+            for (int rt = 0; rt < NRT; ++rt) pow2[rt] = pow2_next[rt];
         }
         kstep(0, true, false, false, dma_mid ? 2 : -1, dma_mid ? 3 : -1, t + 2, pbuf, false, first, false);
         kstep(1, true, false, false, dma_mid ? 4 : -1, dma_mid ? 5 : -1, t + 2, pbuf, false, false, false);
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         buf = (buf + 1 == kRing) ? 0 : buf + 1;
     };
 
-    const bool active = wm * 128 < rows;
+    const bool active = wm * (NTT * 32) < rows;
 #ifdef SGLK_DEV_ABLATE
     unsigned long long t0 = 0, r0 = 0;
     if (p.dbg && tid == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -458,12 +467,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // DMA / wait flags stay literals.
     if (active) {
         // operands of (stage 0, k-step 0)
-        ld_w(0, 0, 0);
-        ld_w(1, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) ld_x(0, tt, 0, 0);
-        cvt2(0, 0, 0, pow2[0]); cvt2(0, 0, 1, pow2[0]);
-        cvt2(0, 1, 0, pow2[1]); cvt2(0, 1, 1, pow2[1]);
+        for (int rt = 0; rt < NRT; ++rt) ld_w(rt, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) ld_x(0, tt, 0, 0);
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) { cvt2(0, rt, 0, pow2[rt]); cvt2(0, rt, 1, pow2[rt]); }
         SGLK_FENCE();
         int t = 0;
         for (; t + 4 < T; t += 2) {
@@ -522,36 +531,43 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     constexpr int kCols = (MODE == MODE_GATE_UP) ? 128 : 256;   // output columns per workgroup
     constexpr int kRowB = kCols * 2;                            // bytes per token row in the image
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
+    for (int tt = 0; tt < NTT; ++tt) {
         if (!active) break;
-        const int r = wm * 128 + tt * 32 + r32e;
+        const int r = wm * (NTT * 32) + tt * 32 + r32e;
         unsigned char* rowp = smem + r * kRowB;
         if (MODE == MODE_GATE_UP) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float g4[4], u4[4];
+            for (int gt = 0; gt < NRT / 2; ++gt) {   // gate row tile gt, up row tile gt + NRT/2: the same 32 ic1 columns
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { g4[i] = acc[0][tt][rg * 4 + i] * mant[0]; u4[i] = acc[1][tt][rg * 4 + i] * mant[1]; }
-                uint2 v;
-                v.x = pack_bf16x2(silu_f32(g4[0]) * u4[0], silu_f32(g4[1]) * u4[1]);
-                v.y = pack_bf16x2(silu_f32(g4[2]) * u4[2], silu_f32(g4[3]) * u4[3]);
-                const int col = wn * 32 + rg * 8 + he * 4;            // 4 consecutive ic1 columns
-                const int chunk = (col >> 3) ^ (r & 15);
-                *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
+                for (int rg = 0; rg < 4; ++rg) {
+                    float g4[4], u4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        g4[i] = acc[gt][tt][rg * 4 + i] * mant[gt];
+                        u4[i] = acc[gt + NRT / 2][tt][rg * 4 + i] * mant[gt + NRT / 2];
+                    }
+                    uint2 v;
+                    v.x = pack_bf16x2(silu_f32(g4[0]) * u4[0], silu_f32(g4[1]) * u4[1]);
+                    v.y = pack_bf16x2(silu_f32(g4[2]) * u4[2], silu_f32(g4[3]) * u4[3]);
+                    const int col = wn * (NRT * 16) + gt * 32 + rg * 8 + he * 4;   // 4 consecutive ic1 columns
+                    const int chunk = (col >> 3) ^ (r & 15);
+                    *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
+                }
             }
         } else {
             float tw = 1.f;
             if (MODE == MODE_DOWN) tw = tw_tab[r];
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < NRT; ++rt) {
                 const float sc_w = mant[rt] * tw;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     float o4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i] * sc_w;
+                    const int col = wn * (NRT * 32) + rt * 32 + rg * 8 + he * 4;
                     if (MODE == MODE_PLAIN) {   // dense epilogue: + bias[col] + addend[row][col] * scale, in fp32
-                        const int gc = ntile * kCols + wn * 64 + rt * 32 + rg * 8 + he * 4;
+                        const int gc = ntile * kCols + col;
                         if (p.bias) {
                             const float4 b = *reinterpret_cast<const float4*>(p.bias + gc);
                             o4[0] += b.x; o4[1] += b.y; o4[2] += b.z; o4[3] += b.w;
@@ -567,7 +583,6 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
                     uint2 v;
                     v.x = pack_bf16x2(o4[0], o4[1]);
                     v.y = pack_bf16x2(o4[2], o4[3]);
-                    const int col = wn * 64 + rt * 32 + rg * 8 + he * 4;
                     const int chunk = (col >> 3) ^ (r & 15);
                     *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = v;
                 }
@@ -629,17 +644,23 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
     static const char* force = getenv("SGLK_PERSIST");   // "0" / "1" override for A/B runs
     const bool persist = force ? force[0] == '1' : p.C <= 1024;
     if (blocks > cus && persist) blocks = cus;
+    static const bool wide_n = getenv("SGLK_WIDE_N") != nullptr;   // wave layout 2(n) x 4(m) instead of 4(n) x 2(m)
     if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
     if (mode == MODE_PLAIN) {
-        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+        if (wide_n) hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
         SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256x");
         return SGLK_OK;
     }
 #define SGLK_LAUNCH256X(R)                                                                                             \
-    if (mode == MODE_GATE_UP)                                                                                          \
-        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_GATE_UP, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
+    if (mode == MODE_GATE_UP && wide_n)                                                                                \
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_GATE_UP, R, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
+    else if (mode == MODE_GATE_UP)                                                                                     \
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_GATE_UP, R, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
+    else if (wide_n)                                                                                                   \
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_DOWN, R, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p); \
     else                                                                                                               \
-        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_DOWN, R>), dim3((unsigned)blocks), dim3(512), 0, stream, p)
+        hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_DOWN, R, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p)
 #ifdef SGLK_DEV_ABLATE   // developer-only timing ablations (wrong results by design)
     static const int abl = getenv("SGLK_RESCALE") ? atoi(getenv("SGLK_RESCALE")) : 0;
     switch (abl) {
