@@ -17,7 +17,7 @@ struct StageTimer {
 };
 
 struct Workspace {
-    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, ic1, ic2, xq, xs, ic1q, ic1s, total;
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tickets, ic1, ic2, xq, xs, ic1q, ic1s, total;
 };
 
 // Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E):
@@ -59,6 +59,7 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     w.expert_off = take((size_t)(E + 1) * sizeof(int));
     w.tile_info = take((size_t)max_tiles * 4 * sizeof(int));
     w.num_tiles = take(sizeof(int));
+    w.tickets = take(16 * sizeof(int));
     w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
     if (wtype == SGLK_W_INT8) {   // W8A8: dynamically quantised activations of both GEMMs
@@ -169,6 +170,11 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g1.out = ic1;
         g1.out_stride = N;
         g1.topk_weights = nullptr;
+        if (tile_m == 256) {   // per-XCD tile tickets of the two persistent launches (8 counters each), zeroed per call
+            int* tickets = (int*)(ws + w.tickets);
+            if (hipMemsetAsync(tickets, 0, 16 * sizeof(int), s) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: ticket reset failed");
+            g1.tickets = tickets;
+        }
 #ifdef SGLK_DEV_ABLATE
         if (const char* dp = getenv("SGLK_DBG_PTR")) g1.dbg = (unsigned long long*)strtoull(dp, nullptr, 16);
 #endif
@@ -202,6 +208,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.out = ic2;
         g2.out_stride = K;
         g2.topk_weights = a->topk_weights;
+        if (g1.tickets) g2.tickets = g1.tickets + 8;
 #ifdef SGLK_DEV_ABLATE
         if (g1.dbg) g2.dbg = g1.dbg + 32 * 8192;
 #endif

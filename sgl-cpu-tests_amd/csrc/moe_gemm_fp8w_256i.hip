@@ -38,7 +38,8 @@ constexpr int kRing = 3;
 constexpr int kScaleOff = kRing * kStage; // 144 KiB, then the scale table
 constexpr int kMaxKBlocks = 64;           // reduction length <= 8192
 constexpr int kRowTabOff = kScaleOff + 16 * kMaxKBlocks * 4;   // + 4 KiB, then the per-row tables of the DOWN epilogue
-constexpr int kLds = kRowTabOff + 2 * kBM * 4;           // + 2 KiB: output slot and routing weight per tile row
+constexpr int kTicketOff = kRowTabOff + 2 * kBM * 4;    // + 2 KiB: output slot and routing weight per tile row
+constexpr int kLds = kTicketOff + 16;                   // + the next dynamic tile ticket of the workgroup
 
 SGLK_DEV void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0); }
 
@@ -93,8 +94,15 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         xl = q + (x < r ? 1 : 0);
         nbx = ((int)gridDim.x - x + 7) >> 3;   // workgroups of this launch on XCD x
     }
+    // Tile sequence of the workgroup inside its XCD's range: four static rounds (j0 + k * nbx), then tickets from a
+    // per-XCD counter (p.tickets, zeroed by the caller) -- a workgroup that drew cheap tail tiles simply draws again, like
+    // hardware dispatch would, while the table prefetch below keeps its one-tile lookahead.  A ticket is requested
+    // after one main loop and published (LDS) after the next, so its latency never shows.
     int jt = blockIdx.x >> 3;
     if (jt >= xl) return;
+    int jt_n = jt + nbx, jt_nn = jt + 2 * nbx;
+    int* ticket_lds = reinterpret_cast<int*>(smem + kTicketOff);
+    int my_ticket = -1;
 
     // What a tile needs before its first LDS-DMA can go out sits behind two dependent round trips (tile table ->
     // row table / scales).  For every tile but the first they are taken during the PREVIOUS tile: the table entry is
@@ -152,12 +160,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
     const int L = xs + jt;
-    const bool has_next_tile = jt + nbx < xl;
+    const bool has_next_tile = jt_n < xl;
     // next tile's table entry by SCALAR load (uniform address, constant address space): lands in SGPRs, costs no
     // VGPR across the main loop and is consumed after it
     if (has_next_tile) {
         const __attribute__((address_space(4))) int* tp = reinterpret_cast<const __attribute__((address_space(4))) int*>(
-            reinterpret_cast<uintptr_t>(p.tile_info + (L + nbx) / p.n_tiles));
+            reinterpret_cast<uintptr_t>(p.tile_info + (xs + jt_n) / p.n_tiles));
         nxt.ti.x = tp[0];
         nxt.ti.y = tp[1];
         nxt.ti.z = tp[2];
@@ -515,7 +523,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     }
 #endif
 
-    if (has_next_tile) fetch_meta(L + nbx, nxt);   // dependent row / scale loads of the next tile fly during the epilogue
+    if (has_next_tile) fetch_meta(xs + jt_n, nxt);   // dependent row / scale loads of the next tile fly during the epilogue
+    if (tid == 0) {
+        // publish the tile after jt_nn: the ticket requested one tile ago, or the static stride (first tile, no counter)
+        ticket_lds[0] = (p.tickets && my_ticket >= 0) ? 4 * nbx + my_ticket : jt_nn + nbx;
+        if (p.tickets) my_ticket = atomicAdd(p.tickets + (blockIdx.x & 7), 1);
+    }
 
     // ---- epilogue: accumulator -> LDS image [token][column] (16-B chunks XOR-swizzled by token&15) -> rows ------
     // 32x32 accumulator: lane = token column (l&31); register i = weight row (i&3) + 8*(i>>2) + 4*(l>>5) of the tile
@@ -622,8 +635,10 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     if (!has_next_tile) break;
     if (MODE == MODE_DOWN && nxt.my_slot >= 0) nxt.tw = p.topk_weights[nxt.my_slot];
     cur = nxt;
-    jt += nbx;
+    jt = jt_n;
+    jt_n = jt_nn;
     __syncthreads();   // the image and the row tables are dead: the next tile's DMA and tables may overwrite them
+    jt_nn = __builtin_amdgcn_readfirstlane(ticket_lds[0]);
     }   // tile loop
 }
 

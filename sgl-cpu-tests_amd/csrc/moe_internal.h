@@ -32,6 +32,7 @@ struct MoeGemmParams {
     const uint16_t* addend;       // PLAIN: bf16 [rows][out columns] added as addend * addend_scale, or null
     int64_t addend_stride;
     float addend_scale;
+    int* tickets;                 // persistent 256-tile kernel: 8 zeroed counters (one per XCD) or null = static tile split
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 

@@ -65,6 +65,25 @@ def bench_moe():
         emit(op="fused_experts_fp8", M=M, experts_touched=touched, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
              tokens_per_s=round(M / ms * 1e3), algorithmic_gb=round(byts / 1e9, 4), gbps=round(byts / ms / 1e6, 1),
              bound="mfma" if t_mfma > t_hbm else "hbm", roofline_frac=round(max(t_mfma, t_hbm) * 1e3 / ms, 4))
+        if M <= 64:
+            # decode-size calls are bound by the host enqueue of the four launches; the library never allocates or
+            # synchronises, so the call can be captured once and replayed as a hipGraph (what a serving loop does)
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for i in range(2):
+                        ops.fused_experts_cpu(a, w1p[0], w2p[0], tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out_g = ops.fused_experts_cpu(a, w1p[0], w2p[0], tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
+                msg = timed(lambda i: graph.replay(), 50)
+                emit(op="fused_experts_fp8_hipgraph_replay", M=M, ms=round(msg, 4), tokens_per_s=round(M / msg * 1e3),
+                     gbps=round(byts / msg / 1e6, 1), roofline_frac=round(max(t_mfma, t_hbm) * 1e3 / msg, 4))
+                del graph, out_g
+            except Exception as ex:   # capture support differs between torch builds: report, do not fail the sweep
+                emit(op="fused_experts_fp8_hipgraph_replay", M=M, error=str(ex)[:200])
 
 
 def bench_moe_literal():
