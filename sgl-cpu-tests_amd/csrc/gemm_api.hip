@@ -256,6 +256,39 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         t.bias = a->bias;
         return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t, t256, s);
     }
+    // W8A8 on the int8 matrix cores (exact int32 accumulation): packed int8 weights, large M
+    if (a->wtype == SGLK_W_INT8 && a->packed && M >= 192 && N % 256 == 0 && K % 64 == 0 && K >= 256 && a->out_type == SGLK_OUT_BF16 &&
+        a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && (int64_t)N * K < (1ll << 32) &&
+        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        const int8_t* xq = (const int8_t*)a->x;
+        int64_t xq_stride = a->x_stride;
+        const float* xs = a->x_scale;
+        if (quant_here) {
+            rc = launch_quant_int8_rows((const uint16_t*)a->x, a->x_stride, (int8_t*)(ws + w.xq), K, (float*)(ws + w.xs),
+                                        M, K, 1e-10f, s);
+            if (rc != SGLK_OK) return rc;
+            xq = (const int8_t*)(ws + w.xq);
+            xq_stride = K;
+            xs = (const float*)(ws + w.xs);
+        }
+        if (xq_stride % 16 == 0 && ((uintptr_t)xq % 16) == 0 && (int64_t)M * xq_stride < (1ll << 32)) {
+            I8GemmParams q{};
+            q.x = xq;
+            q.x_stride = xq_stride;
+            q.x_bytes = (int64_t)M * xq_stride;
+            q.x_scale = xs;
+            q.w = (const uint8_t*)a->w;
+            q.w_bytes = (int64_t)N * K;
+            q.w_scale = a->w_scale;
+            q.bias = a->bias;
+            q.out = (uint16_t*)a->out;
+            q.out_stride = a->out_stride;
+            q.M = M;
+            q.K = K;
+            q.n_tiles = N / 256;
+            return launch_gemm_i8_256(q, s);
+        }
+    }
     const int tiles = (int)ceil_div(M, kGenericTileM);
     rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
     if (rc != SGLK_OK) return rc;

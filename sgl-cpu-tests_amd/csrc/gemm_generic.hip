@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
                 const int c = col0 + nt * 16 + q4 + j;
                 if (c >= p.n_out) continue;
                 float g = acc[nt][j], u = acc[nt + 2][j];
-                if (WTYPE == SGLK_W_INT8) { g *= xs * wcs[c]; u *= xs * wcs[p.n_half + c]; }
+                if (WTYPE == SGLK_W_INT8) { g = xs * g * wcs[c]; u = xs * u * wcs[p.n_half + c]; }   // oracle order: As * C * Bs
                 store(c, silu_f32(g) * u);
             }
     } else {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
                 const int c = col0 + nt * 16 + q4 + j;
                 if (c >= p.n_out) continue;
                 float v = acc[nt][j];
-                if (WTYPE == SGLK_W_INT8) v *= xs * wcs[c];
+                if (WTYPE == SGLK_W_INT8) v = xs * v * wcs[c];   // oracle order: As * C * Bs (test_gemm_int8.py:42)
                 if (p.bias) v += p.bias[c];
                 if (p.addend) v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.addend)[orow * p.addend_stride + c]) * p.addend_scale;
                 store(c, v * tw);

@@ -45,6 +45,23 @@ int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, 
 // the 256x entry point forwards here unless SGLK_G256X is set
 int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
+// ---- dense W8A8 GEMM on the int8 matrix cores (gemm_i8_256.hip) ----------------------------------------------------------
+struct I8GemmParams {
+    const int8_t* x;          // [M][K] int8, row stride x_stride bytes (multiple of 16)
+    int64_t x_stride;
+    int64_t x_bytes;          // extent of x (< 4 GiB, buffer descriptor)
+    const float* x_scale;     // [M]
+    const uint8_t* w;         // packed int8 [N][K] (pack.hip tile order)
+    int64_t w_bytes;          // N * K (< 4 GiB)
+    const float* w_scale;     // [N]
+    const float* bias;        // [N] or null
+    uint16_t* out;            // bf16 [M][N]
+    int64_t out_stride;
+    int M, K;
+    int n_tiles;              // N / 256
+};
+int launch_gemm_i8_256(const I8GemmParams& p, hipStream_t stream);
+
 // ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
 constexpr int kGenericTileM = 64;
 enum { GG_GATE_UP = 0, GG_DOWN = 1, GG_PLAIN = 2 };

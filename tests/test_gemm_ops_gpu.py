@@ -157,7 +157,40 @@ def test_int8_gemm_ops(ops, case):
     assert torch.equal(fused, out), "fused quant+mm must equal the two-step path bit for bit"
     if N % 16 == 0 and K % 64 == 0:
         outp = ops.int8_scaled_mm_cpu(Aq, ops.convert_weight_packed(inp["Bq"]), As, inp["Bs"], bias, torch.bfloat16, True)
-        assert torch.equal(outp, out)
+        if M >= 192 and N % 256 == 0 and K >= 256:
+            # packed + large M runs on the int8 matrix cores with exact int32 sums (test_int8_mfma_gemm_is_exact); the
+            # row-major path accumulates the same products in fp32, which rounds once sums pass 2^24
+            assert ref_pred(g["ref_out"], outp), name
+            assert rel_rms(outp, out) < 2e-3
+        else:
+            assert torch.equal(outp, out)
+
+
+@pytest.mark.parametrize("shape", [(192, 256, 256, False), (1000, 512, 1024, True), (300, 768, 4160, True), (2049, 1536, 2048, False)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_int8_mfma_gemm_is_exact(ops, shape):
+    """Large-M packed int8 GEMM runs on mfma_i32_32x32x32_i8 (csrc/gemm_i8_256.hip): the integer dot products are exact,
+    so the result must equal an exact-integer evaluation of the oracle's expression (As * C * Bs + bias, fp32, one bf16
+    rounding; /root/reference/test_gemm_int8.py:41-47) BIT FOR BIT, and the reference predicate against the float oracle."""
+    M, N, K, has_bias = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) / 10).bfloat16()
+    Bq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    Bs = torch.rand(N, generator=g) * 1e-2 + 1e-4
+    bias = torch.randn(N, generator=g) if has_bias else None
+    Aq, As = ogemm.per_token_quant_int8(A)
+    acc = (Aq.long() @ Bq.long().t())                                   # exact
+    exact = As.float().view(-1, 1) * acc.to(torch.float32) * Bs.view(1, -1)
+    if bias is not None:
+        exact = exact + bias.view(1, -1)
+    exact = exact.bfloat16()
+    wp = ops.convert_weight_packed(Bq.cuda())
+    b = bias.cuda() if bias is not None else None
+    out = ops.int8_scaled_mm_cpu(Aq.cuda(), wp, As.cuda(), Bs.cuda(), b, torch.bfloat16, True)
+    assert torch.equal(out.cpu(), exact)
+    fused = ops.int8_scaled_mm_with_quant(A.cuda(), wp, Bs.cuda(), b, torch.bfloat16, True)
+    assert torch.equal(fused, out)
+    assert ref_pred(ogemm.int8_scaled_mm(Aq, As, Bq, Bs, bias).bfloat16(), out)
 
 
 def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):

@@ -123,23 +123,29 @@ def bench_moe_literal():
 
 def bench_gemm():
     g = torch.Generator(device="cuda").manual_seed(2)
-    for (M, N, K) in ((1000, 18432, 2560), (128, 4096, 4096), (4096, 1536, 2048)):   # bench_gemm.py:147, config 0, Qwen3 gate_up
+    # bench_gemm.py:147, BASELINE config 0, Qwen3 expert gate_up, Qwen3 dense FFN up / down
+    for (M, N, K) in ((1000, 18432, 2560), (128, 4096, 4096), (4096, 1536, 2048), (4096, 12288, 2048), (4096, 2048, 6144)):
         x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         wb = torch.randn(N, K, device="cuda", generator=g).bfloat16()
         wf = (torch.randn(N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
         wi = torch.randint(-127, 127, (N, K), device="cuda", generator=g, dtype=torch.int8)
         sc = torch.randn(N // 128, K // 128, device="cuda", generator=g) * 1e-3
         wfp = ops.convert_weight_packed(wf)          # the reference benches prepacked weights (bench_gemm.py:64-69)
+        wip = ops.convert_weight_packed(wi)
         si = torch.rand(N, device="cuda", generator=g) * 1e-2
+        xq, xs = ops.per_token_quant_int8_cpu(x)
         flop = 2 * M * N * K
         for name, fn in (
                 ("weight_packed_linear_bf16", lambda i: ops.weight_packed_linear(x, wb, None, False)),
                 ("fp8_scaled_mm_packed", lambda i: ops.fp8_scaled_mm_cpu(x, wfp, sc, [128, 128], None, torch.bfloat16, True)),
                 ("fp8_scaled_mm_rowmajor", lambda i: ops.fp8_scaled_mm_cpu(x, wf, sc, [128, 128], None, torch.bfloat16, False)),
-                ("int8_scaled_mm_with_quant", lambda i: ops.int8_scaled_mm_with_quant(x, wi, si, None, torch.bfloat16, False))):
+                ("int8_scaled_mm_packed", lambda i: ops.int8_scaled_mm_cpu(xq, wip, xs, si, None, torch.bfloat16, True)),
+                ("int8_scaled_mm_with_quant_packed", lambda i: ops.int8_scaled_mm_with_quant(x, wip, si, None, torch.bfloat16, True)),
+                ("int8_scaled_mm_with_quant_rowmajor", lambda i: ops.int8_scaled_mm_with_quant(x, wi, si, None, torch.bfloat16, False))):
             ms = timed(fn, 10)
+            peak = 2 * PEAK_BF16 if name.startswith("int8_scaled_mm") and "rowmajor" not in name else PEAK_BF16   # int8 MFMA: 2x bf16
             emit(op=name, M=M, N=N, K=K, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2),
-                 roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
+                 roofline_frac=round(flop / ms / 1e9 / peak, 4), peak_tflops=peak, bound="mfma")
 
 
 def bench_attn():
