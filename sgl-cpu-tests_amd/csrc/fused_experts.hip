@@ -79,6 +79,16 @@ bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
            getenv("SGLK_FORCE_GENERIC") == nullptr;
 }
 
+// int8 fused_experts on the int8 matrix cores (gemm_i8_256.hip): packed weights, both reduction lengths whole 64-deep
+// stages (>= 4 of them), output tiles whole, and enough rows per expert for 256-token tiles to pay (same threshold as the
+// fp8 path).  32-bit buffer offsets bound the operand sizes.
+bool tuned_int8_ok(const sglk_fused_experts_args* a) {
+    const int64_t S = (int64_t)a->M * a->topk;
+    return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 256 &&
+           S >= (int64_t)44 * a->E && (int64_t)a->M * a->K < (1ll << 32) && S * (int64_t)a->N < (1ll << 32) &&
+           (int64_t)2 * a->N * a->K < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+}
+
 }  // namespace
 
 extern "C" size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
@@ -141,7 +151,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         if (tm) hipEventRecord(tm->at(call, i), s);
     };
     const bool tuned = tuned_fp8_ok(a);
-    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : kGenericTileM;
+    const bool tuned_i8 = tuned_int8_ok(a);
+    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (tuned_i8 ? 256 : kGenericTileM);
     mark(0);
     int rc = sglk_moe_align(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                             ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
@@ -216,6 +227,61 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
                                     : launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s))
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)
                                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else if (tuned_i8) {
+        // W8A8 on the int8 matrix cores: quantise x per token, GEMM-1 (+SiLU*mul, fp32 out), quantise ic1 per row,
+        // GEMM-2 (+routing weight, bf16 rows by slot); /root/reference/test_moe_int8.py:59-94
+        int8_t* xq = (int8_t*)(ws + w.xq);
+        float* xs = (float*)(ws + w.xs);
+        rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q1{};
+        q1.x = xq;
+        q1.x_stride = K;
+        q1.x_bytes = (int64_t)M * K;
+        q1.x_scale = xs;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_bytes = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = 2 * N;
+        q1.out = ic1;                  // fp32 [position][N]
+        q1.out_stride = N;
+        q1.M = M;
+        q1.K = K;
+        q1.n_tiles = N / 128;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.n_half = N;
+        rc = launch_gemm_i8_256(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        int8_t* hq = (int8_t*)(ws + w.ic1q);
+        float* hs = (float*)(ws + w.ic1s);
+        rc = launch_quant_int8_rows_f32((const float*)ic1, N, hq, N, hs, (int64_t)M * topk, N, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q2{};
+        q2.x = hq;
+        q2.x_stride = N;
+        q2.x_bytes = (int64_t)M * topk * N;
+        q2.x_scale = hs;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_bytes = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = K;
+        q2.out = ic2;                  // bf16 [slot][K]
+        q2.out_stride = K;
+        q2.M = M * topk;
+        q2.K = N;
+        q2.n_tiles = K / 256;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.topk_weights = a->topk_weights;
+        rc = launch_gemm_i8_256(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else {

@@ -280,13 +280,14 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
             q.w = (const uint8_t*)a->w;
             q.w_bytes = (int64_t)N * K;
             q.w_scale = a->w_scale;
+            q.scale_rows = N;
             q.bias = a->bias;
             q.out = (uint16_t*)a->out;
             q.out_stride = a->out_stride;
             q.M = M;
             q.K = K;
             q.n_tiles = N / 256;
-            return launch_gemm_i8_256(q, s);
+            return launch_gemm_i8_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
         }
     }
     const int tiles = (int)ceil_div(M, kGenericTileM);

@@ -6,6 +6,11 @@
 // int32 by mfma_i32_32x32x32_i8 (twice the bf16 MFMA rate), the two scales and the bias are applied in fp32 in the
 // oracle's order, one rounding to bf16.
 //
+// The same kernel serves the int8 fused_experts (/root/reference/test_moe_int8.py:59-94, bench_moe.py:89-106) as its two
+// grouped GEMMs: MODE_GATE_UP gathers the per-token-quantised activations through sorted_slot and writes
+// silu(gate) * up in fp32 (the per-row re-quantisation needs the whole row, so it stays a separate pass), MODE_DOWN
+// applies the routing weight and scatters bf16 rows by slot.
+//
 // Tile 256 tokens x 256 weight rows per workgroup, 8 waves (4 along weight rows x 2 along tokens), wave tile 64 x 128 =
 // 2 x 4 MFMA tiles, 128 int32 accumulators per lane, 2 waves per SIMD.  K in 64-deep stages (two k-steps of 32) through
 // a ring of FOUR LDS buffers (X 16 KiB + W 16 KiB each): both operands arrive by LDS-DMA three stages ahead, one counted
@@ -36,9 +41,10 @@ constexpr int kStageX = kBM * 64;          // 16 KiB
 constexpr int kStageW = 16 * 1024;         // 16 packed 16x64 tiles
 constexpr int kStage = kStageX + kStageW;  // 32 KiB
 constexpr int kRing = 4;
-constexpr int kTabOff = kRing * kStage;    // 128 KiB, then xs[256], ws[256], bias[256] (f32)
-constexpr int kLds = kTabOff + 3 * 256 * 4;
+constexpr int kTabOff = kRing * kStage;    // 128 KiB, then xs[256], ws[256], bias-or-routing-weight[256] (f32), slot[256]
+constexpr int kLds = kTabOff + 4 * 256 * 4;
 
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
 
@@ -47,33 +53,67 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
 
-    const int mtiles = (p.M + kBM - 1) / kBM;
-    const int live = mtiles * p.n_tiles;
-    if ((int)blockIdx.x >= live) return;
-    // consecutive workgroups of an XCD share the activation rows (same m-tile) and walk the weight row tiles
-    const int L = xcd_remap(blockIdx.x, live);
-    const int mtile = L / p.n_tiles;
-    const int ntile = L - mtile * p.n_tiles;
-    const int pos0 = mtile * kBM;
-    const int rows = (p.M - pos0 < kBM) ? p.M - pos0 : kBM;
+    int live, e = 0, pos0, rows, mtile, ntile;
+    if (p.tile_info) {   // grouped: m-tile table of moe_align (tile_m = 256)
+        live = p.num_tiles[0] * p.n_tiles;
+        if ((int)blockIdx.x >= live) return;
+        const int L = xcd_remap(blockIdx.x, live);
+        mtile = L / p.n_tiles;
+        ntile = L - mtile * p.n_tiles;
+        const int4 ti = p.tile_info[mtile];
+        e = __builtin_amdgcn_readfirstlane(ti.x);
+        pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+        rows = __builtin_amdgcn_readfirstlane(ti.z);
+    } else {             // dense: rows in natural order
+        const int mtiles = (p.M + kBM - 1) / kBM;
+        live = mtiles * p.n_tiles;
+        if ((int)blockIdx.x >= live) return;
+        // consecutive workgroups of an XCD share the activation rows (same m-tile) and walk the weight row tiles
+        const int L = xcd_remap(blockIdx.x, live);
+        mtile = L / p.n_tiles;
+        ntile = L - mtile * p.n_tiles;
+        pos0 = mtile * kBM;
+        rows = (p.M - pos0 < kBM) ? p.M - pos0 : kBM;
+    }
+    // workgroup's 16 weight row-tiles: GATE_UP = 8 gate + 8 up (the same 128 ic1 columns), else 16 consecutive
+    auto piece_row16 = [&](int piece) {
+        if (MODE == MODE_GATE_UP) return (piece < 8) ? ntile * 8 + piece : (p.n_half >> 4) + ntile * 8 + (piece - 8);
+        return ntile * 16 + piece;
+    };
     const int T = p.K >> 6;   // 64-deep stages, >= 4 (launcher)
 
     float* xs_tab = reinterpret_cast<float*>(smem + kTabOff);
     float* ws_tab = xs_tab + 256;
-    float* bias_tab = ws_tab + 256;
+    float* bias_tab = ws_tab + 256;                       // PLAIN: bias per column; DOWN: routing weight per row
+    int* slot_tab = reinterpret_cast<int*>(bias_tab + 256);   // DOWN: output row (slot) per tile row
     // per-row / per-column epilogue factors: fetched now, parked in registers, written to LDS after the DMA is out
-    float my_xs = 0.f, my_ws = 0.f, my_bias = 0.f;
+    float my_a = 0.f, my_b = 0.f;
+    int my_slot = -1;
+    int64_t my_xrow = 0;      // x row of tile row `tid` (tid < 256)
     if (tid < kBM) {
-        if (tid < rows) my_xs = p.x_scale[pos0 + tid];
+        if (tid < rows) {
+            if (MODE == MODE_GATE_UP) {
+                my_slot = p.sorted_slot[pos0 + tid];
+                my_xrow = my_slot / p.topk;
+            } else {
+                my_xrow = pos0 + tid;
+                if (MODE == MODE_DOWN) my_slot = p.sorted_slot[pos0 + tid];
+            }
+            my_a = p.x_scale[my_xrow];
+            if (MODE == MODE_DOWN) my_b = p.topk_weights[my_slot];
+        }
     } else {
-        const int c = ntile * 256 + (tid - 256);
-        my_ws = p.w_scale[c];
-        if (p.bias) my_bias = p.bias[c];
+        const int c = tid - 256;
+        const float* sc_e = p.w_scale + (int64_t)e * p.scale_rows;
+        if (MODE == MODE_GATE_UP) my_a = sc_e[c < 128 ? ntile * 128 + c : p.n_half + ntile * 128 + (c - 128)];
+        else my_a = sc_e[ntile * 256 + c];
+        if (MODE == MODE_PLAIN && p.bias) my_b = p.bias[ntile * 256 + c];
     }
 
     // ---- LDS-DMA sources ------------------------------------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)e * p.w_bytes), 0, (unsigned)p.w_bytes, 0x00020000);
     const int ctiles = p.K >> 6;
     // X piece i of the wave (i = 0,1): image rows (wave*2+i)*16 + (lane>>2), LDS chunk lane&3 <- source chunk ^ swizzle
     unsigned xsrc[2], wsrc[2];
@@ -81,8 +121,10 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     for (int i = 0; i < 2; ++i) {
         const int r = (wave * 2 + i) * 16 + (lane >> 2);
         const int rr = r < rows ? r : 0;
-        xsrc[i] = (unsigned)((int64_t)(pos0 + rr) * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
-        wsrc[i] = (unsigned)((ntile * 16 + wave * 2 + i) * ctiles) * 1024u + lane * 16;
+        int64_t xrow = pos0 + rr;
+        if (MODE == MODE_GATE_UP) xrow = p.sorted_slot[pos0 + rr] / p.topk;
+        xsrc[i] = (unsigned)(xrow * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+        wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * ctiles) * 1024u + lane * 16;
     }
     auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // i = 0,1: X rows; 2,3: packed W tiles
         unsigned char* sx = smem + buf * kStage;
@@ -97,7 +139,11 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     const int h = lane >> 5, r32 = lane & 31;
     int wbase[2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) wbase[rt] = (wn * 4 + rt * 2 + (r32 >> 4)) * 1024 + (r32 & 15) * 16;
+    for (int rt = 0; rt < 2; ++rt) {
+        // GATE_UP: row tile 0 = gate pieces wn*2.., row tile 1 = the matching up pieces (same columns, same lane)
+        const int piece0 = (MODE == MODE_GATE_UP) ? (rt == 0 ? wn * 2 : 8 + wn * 2) : wn * 4 + rt * 2;
+        wbase[rt] = (piece0 + (r32 >> 4)) * 1024 + (r32 & 15) * 16;
+    }
     auto woff = [&](int rt, int ks) __attribute__((always_inline)) { return wbase[rt] + (2 * ks + h) * 256; };
     const int xrow0 = wm * 128 + r32;
     auto xoff = [&](int tt, int ks) __attribute__((always_inline)) {
@@ -121,8 +167,13 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
             for (int i = 0; i < 4; ++i) issue_piece(st, st, i);
         }
     }
-    if (tid < kBM) xs_tab[tid] = my_xs;
-    else { ws_tab[tid - 256] = my_ws; bias_tab[tid - 256] = my_bias; }
+    if (tid < kBM) {
+        xs_tab[tid] = my_a;
+        if (MODE == MODE_DOWN) { bias_tab[tid] = my_b; slot_tab[tid] = my_slot; }
+    } else {
+        ws_tab[tid - 256] = my_a;
+        if (MODE == MODE_PLAIN) bias_tab[tid - 256] = my_b;
+    }
     // stage 0 landed (its four pieces are the oldest of up to 16), tables visible
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // T >= 4
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -244,35 +295,65 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     }
 #undef SGLK_FENCE
 
-    // ---- epilogue: int32 -> fp32, scales and bias in the oracle's order, bf16 image in LDS, whole rows out -------------
+    // ---- epilogue: int32 -> fp32, scales in the oracle's order (As * C * Bs), image in LDS, whole rows out ---------------
+    // image rows are 512 B either way: 256 bf16 columns (PLAIN / DOWN) or 128 fp32 columns (GATE_UP)
     __syncthreads();   // every wave is done reading the ring
-    constexpr int kRowB = 256 * 2;
+    constexpr int kRowB = 512;
     if (active) {
         float xs4[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) xs4[tt] = xs_tab[wm * 128 + tt * 32 + r32];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        if (MODE == MODE_GATE_UP) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                // the column factors are fetched once per (row tile, register group) and used for the four token tiles
-                const int col = wn * 64 + rt * 32 + rg * 8 + h * 4;
-                const float4 w4 = *reinterpret_cast<const float4*>(ws_tab + col);
-                const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + col);
+                const int col = wn * 32 + rg * 8 + h * 4;            // 4 consecutive ic1 columns
+                const float4 wg = *reinterpret_cast<const float4*>(ws_tab + col);
+                const float4 wu = *reinterpret_cast<const float4*>(ws_tab + 128 + col);
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const int r = wm * 128 + tt * 32 + r32;
                     const float xs = xs4[tt];
-                    float o4[4];   // (xs * acc) * ws + bias, separately rounded like the oracle's torch expression
-                    o4[0] = xs * (float)acc[rt][tt][rg * 4 + 0] * w4.x + b4.x;
-                    o4[1] = xs * (float)acc[rt][tt][rg * 4 + 1] * w4.y + b4.y;
-                    o4[2] = xs * (float)acc[rt][tt][rg * 4 + 2] * w4.z + b4.z;
-                    o4[3] = xs * (float)acc[rt][tt][rg * 4 + 3] * w4.w + b4.w;
-                    uint2 v;
-                    v.x = pack_bf16x2(o4[0], o4[1]);
-                    v.y = pack_bf16x2(o4[2], o4[3]);
-                    const int chunk = (col >> 3) ^ (r & 15);
-                    *reinterpret_cast<uint2*>(smem + r * kRowB + chunk * 16 + (col & 4) * 2) = v;
+                    float4 v;
+                    v.x = silu_f32(xs * (float)acc[0][tt][rg * 4 + 0] * wg.x) * (xs * (float)acc[1][tt][rg * 4 + 0] * wu.x);
+                    v.y = silu_f32(xs * (float)acc[0][tt][rg * 4 + 1] * wg.y) * (xs * (float)acc[1][tt][rg * 4 + 1] * wu.y);
+                    v.z = silu_f32(xs * (float)acc[0][tt][rg * 4 + 2] * wg.z) * (xs * (float)acc[1][tt][rg * 4 + 2] * wu.z);
+                    v.w = silu_f32(xs * (float)acc[0][tt][rg * 4 + 3] * wg.w) * (xs * (float)acc[1][tt][rg * 4 + 3] * wu.w);
+                    const int chunk = (col >> 2) ^ (r & 15);         // 16-byte chunk = 4 fp32 columns
+                    *reinterpret_cast<float4*>(smem + r * kRowB + chunk * 16) = v;
+                }
+            }
+        } else {
+            float tw4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MODE == MODE_DOWN) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) tw4[tt] = bias_tab[wm * 128 + tt * 32 + r32];
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    // the column factors are fetched once per (row tile, register group) and used for the four token tiles
+                    const int col = wn * 64 + rt * 32 + rg * 8 + h * 4;
+                    const float4 w4 = *reinterpret_cast<const float4*>(ws_tab + col);
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (MODE == MODE_PLAIN) b4 = *reinterpret_cast<const float4*>(bias_tab + col);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const int r = wm * 128 + tt * 32 + r32;
+                        const float xs = xs4[tt];
+                        float o4[4];   // (xs * acc) * ws (+ bias | * routing weight), separately rounded like the oracle
+                        o4[0] = xs * (float)acc[rt][tt][rg * 4 + 0] * w4.x;
+                        o4[1] = xs * (float)acc[rt][tt][rg * 4 + 1] * w4.y;
+                        o4[2] = xs * (float)acc[rt][tt][rg * 4 + 2] * w4.z;
+                        o4[3] = xs * (float)acc[rt][tt][rg * 4 + 3] * w4.w;
+                        if (MODE == MODE_PLAIN) { o4[0] += b4.x; o4[1] += b4.y; o4[2] += b4.z; o4[3] += b4.w; }
+                        if (MODE == MODE_DOWN) { o4[0] *= tw4[tt]; o4[1] *= tw4[tt]; o4[2] *= tw4[tt]; o4[3] *= tw4[tt]; }
+                        uint2 v;
+                        v.x = pack_bf16x2(o4[0], o4[1]);
+                        v.y = pack_bf16x2(o4[2], o4[3]);
+                        const int chunk = (col >> 3) ^ (r & 15);
+                        *reinterpret_cast<uint2*>(smem + r * kRowB + chunk * 16 + (col & 4) * 2) = v;
+                    }
                 }
             }
         }
@@ -285,21 +366,29 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
         const int idx = it * 512 + tid;
         const int r = idx / kChunksPerRow;
         const int pc = idx - r * kChunksPerRow;
-        const int lc = pc ^ (r & 15);
+        const int lc = pc ^ (r & 15);                  // logical chunk: 8 bf16 or 4 fp32 columns
         if (r < rows) {
             const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
-            *reinterpret_cast<uint4*>(p.out + (int64_t)(pos0 + r) * p.out_stride + ntile * 256 + lc * 8) = v;
+            if (MODE == MODE_GATE_UP) {
+                float* orow = reinterpret_cast<float*>(p.out) + (int64_t)(pos0 + r) * p.out_stride + ntile * 128;
+                *reinterpret_cast<uint4*>(orow + lc * 4) = v;
+            } else {
+                const int64_t orow = (MODE == MODE_DOWN) ? (int64_t)slot_tab[r] : (int64_t)(pos0 + r);
+                *reinterpret_cast<uint4*>(p.out + orow * p.out_stride + ntile * 256 + lc * 8) = v;
+            }
         }
     }
 }
 
 }  // namespace gi8
 
-int launch_gemm_i8_256(const I8GemmParams& p, hipStream_t stream) {
-    if (p.M <= 0) return SGLK_OK;
+int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream) {
     if (p.K < 256 || p.K % 64 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_256: reduction length %d must be a multiple of 64 and >= 256", p.K);
-    const int64_t blocks = ceil_div(p.M, gi8::kBM) * p.n_tiles;
-    hipLaunchKernelGGL(gi8::gemm_i8_256_kernel, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks <= 0) return SGLK_OK;
+    if (mode == MODE_GATE_UP) hipLaunchKernelGGL(gi8::gemm_i8_256_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    else if (mode == MODE_DOWN) hipLaunchKernelGGL(gi8::gemm_i8_256_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gi8::gemm_i8_256_kernel<MODE_PLAIN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     SGLK_CHECK_LAUNCH("gemm_i8_256");
     return SGLK_OK;
 }

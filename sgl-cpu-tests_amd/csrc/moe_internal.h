@@ -47,20 +47,28 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
 
 // ---- dense W8A8 GEMM on the int8 matrix cores (gemm_i8_256.hip) ----------------------------------------------------------
 struct I8GemmParams {
-    const int8_t* x;          // [M][K] int8, row stride x_stride bytes (multiple of 16)
+    const int8_t* x;          // [rows][K] int8, row stride x_stride bytes (multiple of 16)
     int64_t x_stride;
     int64_t x_bytes;          // extent of x (< 4 GiB, buffer descriptor)
-    const float* x_scale;     // [M]
-    const uint8_t* w;         // packed int8 [N][K] (pack.hip tile order)
-    int64_t w_bytes;          // N * K (< 4 GiB)
-    const float* w_scale;     // [N]
-    const float* bias;        // [N] or null
-    uint16_t* out;            // bf16 [M][N]
-    int64_t out_stride;
-    int M, K;
-    int n_tiles;              // N / 256
+    const float* x_scale;     // per x row
+    const uint8_t* w;         // packed int8 [E][R][K] (pack.hip tile order)
+    int64_t w_bytes;          // bytes per expert = R * K (< 4 GiB)
+    const float* w_scale;     // [E][scale_rows] per weight row
+    int scale_rows;           // R
+    const float* bias;        // PLAIN: [R] or null
+    uint16_t* out;            // PLAIN: bf16 [M][R]; GATE_UP: fp32 ic1 [position][N]; DOWN: bf16 ic2 [slot][R]
+    int64_t out_stride;       // elements of the output type
+    int M, K;                 // dense: rows of x; K = reduction length
+    int n_tiles;              // PLAIN / DOWN: R / 256; GATE_UP: N / 128
+    // grouped (fused_experts): m-tile table with tile_m = 256; null = dense
+    const int4* tile_info;
+    const int* num_tiles;
+    const int* sorted_slot;
+    int topk;
+    int n_half;               // GATE_UP: N = row offset of the up half of w1
+    const float* topk_weights;   // DOWN
 };
-int launch_gemm_i8_256(const I8GemmParams& p, hipStream_t stream);
+int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 
 // ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
 constexpr int kGenericTileM = 64;

@@ -71,6 +71,33 @@ def test_fused_experts_int8(ops, case, prepack):
     assert ref_pred(ref, out), name
 
 
+@pytest.mark.parametrize("shape", [(1024, 768, 2048, 16, 4), (1000, 256, 512, 4, 2), (3000, 384, 1024, 32, 8)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_int8_on_int8_mfma(ops, shape):
+    """Large-M packed int8 fused_experts runs both grouped GEMMs on mfma_i32_32x32x32_i8 (csrc/gemm_i8_256.hip); checked
+    against the restated oracle (oracle/moe.py, /root/reference/test_moe_int8.py:59-94) with the reference's own bars,
+    against the generic engine (row-major weights), for ragged expert loads and masked slots."""
+    M, N, K, E, topk = shape
+    inp = recipes.moe_int8_inputs(M, N, K, E, topk, 4000 + M)
+    ids = inp["topk_ids"].clone()
+    ids[::7, 0] = -1                                         # some masked slots (offloading contract)
+    ref = moe.fused_experts_int8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["topk_weight"], ids).float()
+    d = cuda(inp)
+    idc = ids.cuda()
+    w1p, w2p = ops.convert_weight_packed(d["w1"]), ops.convert_weight_packed(d["w2"])
+    out = ops.fused_experts_cpu(d["a"].clone(), w1p, w2p, d["topk_weight"], idc, False, True, False, d["w1s"], d["w2s"],
+                                None, None, None, True)
+    mre = (out.float().cpu() - ref).abs().mean() / ref.abs().mean()
+    assert mre < 0.01, f"mean relative error {mre:.4f}"
+    assert ref_pred(ref, out)
+    generic = ops.fused_experts_cpu(d["a"].clone(), d["w1"], d["w2"], d["topk_weight"], idc, False, True, False, d["w1s"],
+                                    d["w2s"], None, None, None, False)
+    assert rel_rms(out, generic) < 5e-3
+    again = ops.fused_experts_cpu(d["a"].clone(), w1p, w2p, d["topk_weight"], idc, False, True, False, d["w1s"], d["w2s"],
+                                  None, None, None, True)
+    assert torch.equal(out, again), "run-to-run bit identity"
+
+
 # ---- shared_expert ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", recipes.SHARED_CASES, ids=lambda c: c[0])
 def test_shared_expert_bf16_and_int8(ops, case):
