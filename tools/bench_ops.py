@@ -2,7 +2,7 @@
 """Secondary measurements (not the driver's bench.py): the M sweep of fp8 fused_experts and the other
 operators of SURVEY.md §8 at the shapes the reference benches, each against the roofline that bounds it.
 
-    python tools/bench_ops.py [moe|moe_literal|gemm|attn|rows|all] > gpurun_out/bench_ops.json
+    python tools/bench_ops.py [moe|moe_literal|moe_int8|gemm|attn|rows|all] > gpurun_out/bench_ops.json
 
 Prints one JSON object per line.  HIP-event timing on the current stream, warm-up, rotating clones where the working
 set would otherwise sit in the 256 MiB Infinity Cache.
@@ -121,6 +121,25 @@ def bench_moe_literal():
                  tflops=round(M * topk * 6 * N * K / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3))
 
 
+def bench_moe_int8():
+    """int8 W8A8 fused_experts (bench_moe.py:89-106) at the Qwen3-30B-A3B expert shape, prepacked weights."""
+    K, N, E, topk = 2048, 768, 128, 8
+    g = torch.Generator(device="cuda").manual_seed(6)
+    w1 = ops.convert_weight_packed(torch.randint(-127, 128, (E, 2 * N, K), device="cuda", generator=g, dtype=torch.int8))
+    w2 = ops.convert_weight_packed(torch.randint(-127, 128, (E, K, N), device="cuda", generator=g, dtype=torch.int8))
+    w1s = torch.rand(E, 2 * N, device="cuda", generator=g) * 1e-3
+    w2s = torch.rand(E, K, device="cuda", generator=g) * 1e-3
+    for M in (1024, 4096, 16384):
+        a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        score = torch.softmax(torch.randn(M, E, device="cuda", generator=g).bfloat16(), dim=-1, dtype=torch.float32)
+        tw, ids = torch.topk(score, topk)
+        ids = ids.to(torch.int32)
+        ms = timed(lambda i: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, True, False, w1s, w2s, None, None, None, True), 20)
+        flop = M * topk * 6 * N * K
+        emit(op="fused_experts_int8", M=M, ms=round(ms, 4), tops=round(flop / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3),
+             roofline_frac=round(flop / ms / 1e9 / (2 * PEAK_BF16), 4), peak_tops=2 * PEAK_BF16, bound="mfma (int8, 2x bf16)")
+
+
 def bench_gemm():
     g = torch.Generator(device="cuda").manual_seed(2)
     # bench_gemm.py:147, BASELINE config 0, Qwen3 expert gate_up, Qwen3 dense FFN up / down (SURVEY.md §8 a8)
@@ -213,7 +232,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
