@@ -92,10 +92,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # SGLK_DIST_BACKEND=gloo: rehearsal of the multi-rank flow on fewer GPUs than ranks (payloads staged through the host,
+    # ranks share devices round-robin); the real runs use RCCL, one rank per GPU
+    backend = os.environ.get("SGLK_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     import sgl_kernel
     from sgl_kernel import _lib, _ops
@@ -154,7 +162,7 @@ def main():
     t1 = time.perf_counter()
     barrier()
     _ops.set_stage_timer(None)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -190,7 +198,9 @@ def main():
                                    f"(K={K_HIDDEN}, N={N_INTER}, E={N_EXPERTS}, top-{TOPK}), {M} tokens per GPU per step, "
                                    f"inplace=False, {LCLONES} rotating weight/input clones",
                        "tokens_per_gpu": M, "experts_per_gpu": E_local,
-                       "parallelism": "single GPU" if world == 1 else f"ep{world} (RCCL all-to-all dispatch/combine)"},
+                       "parallelism": "single GPU" if world == 1 else
+                       (f"ep{world} (RCCL all-to-all dispatch/combine)" if backend == "nccl" else
+                        f"ep{world} REHEARSAL over {backend}, host-staged payloads, ranks sharing GPUs: not a measurement")},
             "roofline": {"bound": "mfma", "kernel": "g256i::moe_gemm_fp8w_256i_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
                          "achieved": round(gemm1_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm1_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

@@ -32,6 +32,17 @@ class ExpertParallelMoE:
         self.experts_per_rank = num_experts // self.world
         self.local_fn = local_experts_fn
         self.last_stats = {}
+        # gloo has no device all-to-all: with it (CPU tests, single-GPU rehearsals of the multi-rank flow) the payloads
+        # are staged through host memory; with RCCL ("nccl") they stay on the GPU
+        self.host_staged = dist.get_backend(group) == "gloo"
+
+    def _all_to_all(self, out, inp, out_splits=None, in_splits=None):
+        if self.host_staged and out.is_cuda:
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
     def plan(self, topk_ids):
         """Which (rank, token) pairs exchange rows.  Returns (send_tok, send_rank, send_counts[G])."""
@@ -53,7 +64,7 @@ class ExpertParallelMoE:
         send_tok, send_rank, send_counts = self.plan(topk_ids)
 
         recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        self._all_to_all(recv_counts, send_counts)
         send_l = send_counts.tolist()
         recv_l = recv_counts.tolist()                  # host sync: split sizes must live on the host
         R_recv = sum(recv_l)
@@ -67,14 +78,14 @@ class ExpertParallelMoE:
 
         recv_rows = torch.empty(R_recv, K, dtype=hidden.dtype, device=hidden.device)
         recv_meta = torch.empty(R_recv, 2 * topk, dtype=torch.int32, device=hidden.device)
-        dist.all_to_all_single(recv_rows, rows, recv_l, send_l, group=self.group)
-        dist.all_to_all_single(recv_meta, meta, recv_l, send_l, group=self.group)
+        self._all_to_all(recv_rows, rows, recv_l, send_l)
+        self._all_to_all(recv_meta, meta, recv_l, send_l)
 
         partial = self.local_fn(recv_rows, recv_meta[:, topk:].contiguous().view(torch.float32),
                                 recv_meta[:, :topk].contiguous())
 
         back = torch.empty(rows.shape[0], K, dtype=hidden.dtype, device=hidden.device)
-        dist.all_to_all_single(back, partial.contiguous(), send_l, recv_l, group=self.group)
+        self._all_to_all(back, partial.contiguous(), send_l, recv_l)
 
         # fixed-order reduce: segment d holds at most one row per token, segments are added in rank order
         out = torch.zeros(M, K, dtype=torch.float32, device=hidden.device)
