@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Developer tool: per-stage times (library HIP events) of one fused_experts configuration.
+    python tools/stage_probe.py [fp8|int8] [M]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
+import torch
+import sgl_kernel  # noqa
+from sgl_kernel import _lib, _ops
+ops = torch.ops.sgl_kernel
+kind = sys.argv[1] if len(sys.argv) > 1 else "int8"
+M = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+K, N, E, topk = 2048, 768, 128, 8
+g = torch.Generator(device="cuda").manual_seed(6)
+a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+tw, ids = torch.topk(torch.softmax(torch.randn(M, E, device="cuda", generator=g), dim=-1), topk); ids = ids.to(torch.int32)
+if kind == "int8":
+    w1 = ops.convert_weight_packed(torch.randint(-127, 128, (E, 2 * N, K), device="cuda", generator=g, dtype=torch.int8))
+    w2 = ops.convert_weight_packed(torch.randint(-127, 128, (E, K, N), device="cuda", generator=g, dtype=torch.int8))
+    s1 = torch.rand(E, 2 * N, device="cuda", generator=g) * 1e-3; s2 = torch.rand(E, K, device="cuda", generator=g) * 1e-3
+    f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, True, False, s1, s2, None, None, None, True)
+else:
+    w1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    s1 = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3; s2 = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
+    f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, True, s1, s2, [128, 128], None, None, True)
+L = _lib.lib()
+for _ in range(5): f()
+torch.cuda.synchronize()
+timer = L.sglk_stage_timer_create(64)
+_ops.set_stage_timer(timer)
+for _ in range(20): f()
+torch.cuda.synchronize()
+_ops.set_stage_timer(None)
+ms = (ctypes.c_float * _lib.NUM_STAGES)(); calls = ctypes.c_int32(0)
+L.sglk_stage_timer_read(timer, ms, ctypes.byref(calls))
+print(kind, "M", M, {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}, "sum", round(sum(ms), 4))
