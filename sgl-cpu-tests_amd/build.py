@@ -19,6 +19,8 @@ OBJ = os.path.join(HERE, "build", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-I", os.path.join(HERE, "..", "include")]
+if os.environ.get("SGLK_EXTRA_FLAGS"):     # developer experiments, e.g. -DSGLK_DMA_SLOT_A=5
+    FLAGS += os.environ["SGLK_EXTRA_FLAGS"].split()
 if os.environ.get("SGLK_DEV_ABLATE"):      # developer-only timing ablations (wrong results by design)
     FLAGS.append("-DSGLK_DEV_ABLATE")
 

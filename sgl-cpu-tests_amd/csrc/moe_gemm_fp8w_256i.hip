@@ -75,6 +75,13 @@ SGLK_DEV void split_scale(float s_in, float& pow2, float& mant) {
 template <int MODE, int RESCALE, int NRT>
 __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGemmParams p) {
     constexpr int NTT = 8 / NRT;
+    // MFMA slot of a k-step that carries the first of its two LDS-DMA pieces (the second rides in slot 7): 3 = beside the
+    // last operand read, 5 = a conversion-only gap
+#ifdef SGLK_DMA_SLOT_A
+    constexpr int kDmaSlotA = SGLK_DMA_SLOT_A;
+#else
+    constexpr int kDmaSlotA = 3;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
 
     const int tid = threadIdx.x;
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         mma(par, 3);
         SGLK_FENCE();
         feed_reads(3);
-        if (dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
+        if (kDmaSlotA == 3 && dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
         if (resc_lo) rescale(0);
         SGLK_FENCE();
         // slots 4..7
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             mma(par, s2);
             SGLK_FENCE();
             feed_cvt(s2);
+            if (s2 == kDmaSlotA && dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
             if (s2 == 7 && dma_b >= 0) issue_piece(dma_stage, dma_buf, dma_b);
             if (resc_lo) rescale(s2 - 3);
             SGLK_FENCE();

@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsglk.so")
+LIB_PATH = os.environ.get("SGLK_LIB_PATH") or os.path.join(_HERE, "libsglk.so")   # override: developer A/B builds
 
 W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2
 
