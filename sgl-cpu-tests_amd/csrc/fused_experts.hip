@@ -89,6 +89,15 @@ bool tuned_int8_ok(const sglk_fused_experts_args* a) {
            (int64_t)2 * a->N * a->K < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
 }
 
+// bf16 fused_experts on the tuned bf16 kernel (gemm_bf16_256.hip): VNNI-2 packed weights, whole tiles, large M
+bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
+    const int64_t S = (int64_t)a->M * a->topk;
+    return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 128 &&
+           S >= (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+           (int64_t)a->M * a->hidden_stride * 2 < (1ll << 32) && S * (int64_t)a->N * 2 < (1ll << 32) &&
+           (int64_t)4 * a->N * a->K < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+}
+
 }  // namespace
 
 extern "C" size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
@@ -152,7 +161,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     };
     const bool tuned = tuned_fp8_ok(a);
     const bool tuned_i8 = tuned_int8_ok(a);
-    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (tuned_i8 ? 256 : kGenericTileM);
+    const bool tuned_b16 = tuned_bf16_ok(a);
+    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM);
     mark(0);
     int rc = sglk_moe_align(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                             ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
@@ -282,6 +292,46 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         q2.topk = topk;
         q2.topk_weights = a->topk_weights;
         rc = launch_gemm_i8_256(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else if (tuned_b16) {
+        // bf16 experts on the bf16 matrix cores, weights in the reference's packed order (/root/reference/test_moe.py:79-92)
+        Bf16GemmParams q1{};
+        q1.x = (const uint16_t*)a->hidden;
+        q1.x_stride = a->hidden_stride * 2;
+        q1.x_bytes = (int64_t)M * a->hidden_stride * 2;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_bytes = (int64_t)2 * N * K * 2;
+        q1.out = ic1;                  // bf16 [position][N]
+        q1.out_stride = N;
+        q1.M = M;
+        q1.K = K;
+        q1.n_tiles = N / 128;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.n_half = N;
+        rc = launch_gemm_bf16_256(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        Bf16GemmParams q2{};
+        q2.x = ic1;
+        q2.x_stride = (int64_t)N * 2;
+        q2.x_bytes = (int64_t)M * topk * N * 2;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_bytes = (int64_t)K * N * 2;
+        q2.out = ic2;                  // bf16 [slot][K]
+        q2.out_stride = K;
+        q2.M = M * topk;
+        q2.K = N;
+        q2.n_tiles = K / 256;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.topk_weights = a->topk_weights;
+        rc = launch_gemm_bf16_256(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else {

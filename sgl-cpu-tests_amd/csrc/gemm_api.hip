@@ -256,6 +256,25 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         t.bias = a->bias;
         return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t, t256, s);
     }
+    // bf16 with the reference's packed (VNNI-2) weights on the bf16 matrix cores: large M
+    if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && M >= 192 && N % 256 == 0 && K % 32 == 0 && K >= 128 &&
+        a->out_type == SGLK_OUT_BF16 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && a->x_stride % 8 == 0 &&
+        ((uintptr_t)a->x % 16) == 0 && (int64_t)M * a->x_stride * 2 < (1ll << 32) && (int64_t)N * K * 2 < (1ll << 32) &&
+        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        Bf16GemmParams q{};
+        q.x = (const uint16_t*)a->x;
+        q.x_stride = a->x_stride * 2;
+        q.x_bytes = (int64_t)M * a->x_stride * 2;
+        q.w = (const uint8_t*)a->w;
+        q.w_bytes = (int64_t)N * K * 2;
+        q.bias = a->bias;
+        q.out = (uint16_t*)a->out;
+        q.out_stride = a->out_stride;
+        q.M = M;
+        q.K = K;
+        q.n_tiles = N / 256;
+        return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
+    }
     // W8A8 on the int8 matrix cores (exact int32 accumulation): packed int8 weights, large M
     if (a->wtype == SGLK_W_INT8 && a->packed && M >= 192 && N % 256 == 0 && K % 64 == 0 && K >= 256 && a->out_type == SGLK_OUT_BF16 &&
         a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && (int64_t)N * K < (1ll << 32) &&

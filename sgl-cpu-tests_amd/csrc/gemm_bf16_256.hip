@@ -1,0 +1,351 @@
+// bf16 x bf16 GEMM on the bf16 matrix cores with the weights in the REFERENCE's packed order (VNNI-2,
+// packed[R/32][C/2][32][2], the layout /root/reference/test_gemm.py:36-46 pins with a live known-answer test):
+//   dense    out = x . w^T (+ bias)                       torch.ops.sgl_kernel.weight_packed_linear   (test_gemm.py:22-25)
+//   grouped  the two GEMMs of bf16 fused_experts            (test_moe.py:79-92, bench_moe.py:65-82)
+// for large M; small M, row-major weights and odd shapes stay on the generic engine (gemm_generic.hip).
+//
+// Same skeleton as gemm_i8_256.hip: tile 256 tokens x 256 weight rows, 8 waves (4 x 2), wave tile 64 x 128 = 2 x 4
+// tiles of mfma_f32_32x32x16_bf16, K in 32-deep stages (two k-steps) through a ring of four 32-KiB LDS buffers, both
+// operands by LDS-DMA three stages ahead, feed issued MFMA by MFMA.  What differs is the weight operand:
+//   * a 32-row block of the packed weight holds, for every k pair, the 32 rows' (k, k+1) dwords back to back (128 B):
+//     the 16 k pairs of a stage are 2 KiB contiguous in HBM and are copied as they are (two 1-KiB DMA pieces);
+//   * the A operand of lane (row r, k half h) at k-step ks is the four dwords of k pairs 8ks + 4h + j (j = 0..3) at
+//     stride 128 B: four conflict-free ds_read_b32 with immediate offsets -- the k order inside the lane is natural,
+//     so the activation fragments are read exactly as in the other kernels.
+// fp32 accumulation, one rounding to bf16 (GATE_UP: after SiLU*mul; DOWN: after the routing weight).
+#include "sglk_common.h"
+#include "moe_internal.h"
+
+namespace sglk {
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+namespace gb16 {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4v;
+
+constexpr int kBM = 256;
+constexpr int kStageX = kBM * 64;          // 16 KiB
+constexpr int kStageW = 16 * 1024;         // 8 row blocks x 16 k pairs x 32 rows x 4 B
+constexpr int kStage = kStageX + kStageW;  // 32 KiB
+constexpr int kRing = 4;
+constexpr int kTabOff = kRing * kStage;    // 128 KiB, then bias-or-routing-weight[256] (f32), slot[256]
+constexpr int kLds = kTabOff + 2 * 256 * 4;
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+
+    int live, e = 0, pos0, rows, mtile, ntile;
+    if (p.tile_info) {   // grouped: m-tile table of moe_align (tile_m = 256)
+        live = p.num_tiles[0] * p.n_tiles;
+        if ((int)blockIdx.x >= live) return;
+        const int L = xcd_remap(blockIdx.x, live);
+        mtile = L / p.n_tiles;
+        ntile = L - mtile * p.n_tiles;
+        const int4 ti = p.tile_info[mtile];
+        e = __builtin_amdgcn_readfirstlane(ti.x);
+        pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+        rows = __builtin_amdgcn_readfirstlane(ti.z);
+    } else {             // dense: rows in natural order
+        const int mtiles = (p.M + kBM - 1) / kBM;
+        live = mtiles * p.n_tiles;
+        if ((int)blockIdx.x >= live) return;
+        // consecutive workgroups of an XCD share the activation rows (same m-tile) and walk the weight row tiles
+        const int L = xcd_remap(blockIdx.x, live);
+        mtile = L / p.n_tiles;
+        ntile = L - mtile * p.n_tiles;
+        pos0 = mtile * kBM;
+        rows = (p.M - pos0 < kBM) ? p.M - pos0 : kBM;
+    }
+    // workgroup's 8 weight row blocks (32 rows each): GATE_UP = 4 gate + 4 up (the same 128 ic1 columns), else 8 consecutive
+    auto row_block = [&](int rb) {
+        if (MODE == MODE_GATE_UP) return (rb < 4) ? ntile * 4 + rb : (p.n_half >> 5) + ntile * 4 + (rb - 4);
+        return ntile * 8 + rb;
+    };
+    const int T = p.K >> 5;   // 32-deep stages (64 bytes of a row), >= 4 (launcher)
+
+    float* bias_tab = reinterpret_cast<float*>(smem + kTabOff);   // PLAIN: bias per column; DOWN: routing weight per row
+    int* slot_tab = reinterpret_cast<int*>(bias_tab + 256);        // DOWN: output row (slot) per tile row
+    float my_b = 0.f;
+    int my_slot = -1;
+    if (tid < kBM) {
+        if (MODE == MODE_DOWN && tid < rows) {
+            my_slot = p.sorted_slot[pos0 + tid];
+            my_b = p.topk_weights[my_slot];
+        }
+    } else if (MODE == MODE_PLAIN && p.bias) {
+        my_b = p.bias[ntile * 256 + (tid - 256)];
+    }
+
+    // ---- LDS-DMA sources ------------------------------------------------------------------------------------------------
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)e * p.w_bytes), 0, (unsigned)p.w_bytes, 0x00020000);
+    const int kpairs = p.K >> 1;   // k pairs per row = dwords per row of a 32-row block
+    // X piece i of the wave (i = 0,1): image rows (wave*2+i)*16 + (lane>>2), LDS chunk lane&3 <- source chunk ^ swizzle
+    unsigned xsrc[2], wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 16 + (lane >> 2);
+        const int rr = r < rows ? r : 0;
+        int64_t xrow = pos0 + rr;
+        if (MODE == MODE_GATE_UP) xrow = p.sorted_slot[pos0 + rr] / p.topk;
+        xsrc[i] = (unsigned)(xrow * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+        // W piece wave*2+i = row block `wave`, half i of the stage's 16 k pairs (8 pairs x 128 B = 1 KiB)
+        wsrc[i] = (unsigned)(row_block(wave) * kpairs) * 128u + (unsigned)i * 1024u + lane * 16;
+    }
+    auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // i = 0,1: X rows; 2,3: packed W tiles
+        unsigned char* sx = smem + buf * kStage;
+        if (i < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sx + (wave * 2 + i) * 1024), 16, xsrc[i], kt * 64, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(sx + kStageX + (wave * 2 + i - 2) * 1024), 16,
+                                                     wsrc[i - 2], kt * 2048, 0, 0);
+    };
+
+    // ---- operand addressing (A = weights, B = tokens) --------------------------------------------------------------------
+    const int h = lane >> 5, r32 = lane & 31;
+    int wbase[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        // GATE_UP: row tile 0 = gate block wn, row tile 1 = the matching up block (same columns, same lane)
+        const int rb = (MODE == MODE_GATE_UP) ? (rt == 0 ? wn : 4 + wn) : wn * 2 + rt;
+        wbase[rt] = rb * 2048 + h * 512 + r32 * 4;
+    }
+    auto woff = [&](int rt, int ks) __attribute__((always_inline)) { return wbase[rt] + ks * 1024; };   // + j * 128, j = 0..3
+    const int xrow0 = wm * 128 + r32;
+    auto xoff = [&](int tt, int ks) __attribute__((always_inline)) {
+        const int row = xrow0 + tt * 32;
+        return row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0.f;
+
+    // prologue: up to four stages in flight
+#pragma unroll
+    for (int st = 0; st < kRing; ++st) {
+        if (st < T) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece(st, st, i);
+        }
+    }
+    if (tid < kBM) {
+        if (MODE == MODE_DOWN) { bias_tab[tid] = my_b; slot_tab[tid] = my_slot; }
+    } else if (MODE == MODE_PLAIN) {
+        bias_tab[tid - 256] = my_b;
+    }
+    // stage 0 landed (its four pieces are the oldest of up to 16), tables visible
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // T >= 4
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
+    i32x4v wf[2][2], xf[2][4];   // [k-step parity][row tile / token tile]
+    auto ld_w = [&](int par, int rt, int fbuf, int ks) __attribute__((always_inline)) {
+        const unsigned char* wp = smem + fbuf * kStage + kStageX + woff(rt, ks);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[par][rt][j] = *reinterpret_cast<const int*>(wp + j * 128);
+    };
+    auto ld_x = [&](int par, int tt, int fbuf, int ks) __attribute__((always_inline)) {
+        xf[par][tt] = *reinterpret_cast<const i32x4v*>(smem + fbuf * kStage + xoff(tt, ks));
+    };
+    auto mma = [&](int par, int s2) __attribute__((always_inline)) {
+        const int rt = (s2 >> 1) & 1, tt = (s2 & 1) + 2 * (s2 >> 2);
+        acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[par][rt]),
+                                                              __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
+    };
+
+    const bool active = wm * 128 < rows;
+    int buf = 0;
+    // k-step ks (0/1) of the stage in `buf`.  fetch: read the next k-step's operands (k-step 1 of this stage, or
+    // k-step 0 of the next one after the sync).  In k-step 1 the sync point S_t comes after the second MFMA: the next
+    // stage has landed and every wave is done with this stage's buffer, which then receives stage t+4.
+    auto kstep = [&](int t, int ks, bool fetch, bool sync, int wait_pieces, bool refill) __attribute__((always_inline)) {
+        const int par = ks, npar = ks ^ 1;
+        const int nbuf = (buf + 1) & (kRing - 1);
+        const int fbuf = ks ? nbuf : buf;
+        const int fks = ks ^ 1;
+        mma(par, 0);
+        SGLK_FENCE();
+        if (sync) {
+            mma(par, 1);
+            SGLK_FENCE();
+            if (wait_pieces == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (wait_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (fetch) { ld_w(npar, 0, fbuf, fks); ld_w(npar, 1, fbuf, fks); ld_x(npar, 0, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            SGLK_FENCE();
+        } else {
+            if (fetch) { ld_w(npar, 0, fbuf, fks); ld_x(npar, 0, fbuf, fks); }
+            SGLK_FENCE();
+            mma(par, 1);
+            SGLK_FENCE();
+            if (fetch) { ld_w(npar, 1, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            SGLK_FENCE();
+        }
+        mma(par, 2);
+        SGLK_FENCE();
+        if (fetch) ld_x(npar, 2, fbuf, fks);
+        SGLK_FENCE();
+        mma(par, 3);
+        SGLK_FENCE();
+        if (fetch) ld_x(npar, 3, fbuf, fks);
+        if (refill) issue_piece(t + 4, buf, 0);
+        SGLK_FENCE();
+        mma(par, 4);
+        SGLK_FENCE();
+        if (refill) issue_piece(t + 4, buf, 1);
+        SGLK_FENCE();
+        mma(par, 5);
+        SGLK_FENCE();
+        mma(par, 6);
+        SGLK_FENCE();
+        if (refill) issue_piece(t + 4, buf, 2);
+        SGLK_FENCE();
+        mma(par, 7);
+        SGLK_FENCE();
+        if (refill) issue_piece(t + 4, buf, 3);
+        SGLK_FENCE();
+    };
+    auto idle_stage = [&](int t, bool has_next, int wait_pieces, bool refill) __attribute__((always_inline)) {
+        if (has_next) {
+            if (wait_pieces == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (wait_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (refill) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_piece(t + 4, buf, i);
+        }
+        buf = (buf + 1) & (kRing - 1);
+    };
+
+    if (active) {
+        ld_w(0, 0, 0, 0);
+        ld_w(0, 1, 0, 0);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) ld_x(0, tt, 0, 0);
+        SGLK_FENCE();
+        int t = 0;
+        for (; t + 4 < T; ++t) {            // steady state: stage t+4 exists
+            kstep(t, 0, true, false, 0, false);
+            kstep(t, 1, true, true, 8, true);
+            buf = (buf + 1) & (kRing - 1);
+        }
+        // drain (T >= 4, guaranteed by the launcher): stages T-4 .. T-1 without refill; the waits are literals so that
+        // no control flow (and no register spill, whose scratch traffic would corrupt the vmcnt accounting) appears
+        kstep(t, 0, true, false, 0, false);
+        kstep(t, 1, true, true, 8, false);      // T-4: stages T-2, T-1 may still be in flight
+        buf = (buf + 1) & (kRing - 1);
+        ++t;
+        kstep(t, 0, true, false, 0, false);
+        kstep(t, 1, true, true, 4, false);      // T-3: stage T-1 may still be in flight
+        buf = (buf + 1) & (kRing - 1);
+        ++t;
+        kstep(t, 0, true, false, 0, false);
+        kstep(t, 1, true, true, 0, false);      // T-2: everything must have landed
+        buf = (buf + 1) & (kRing - 1);
+        ++t;
+        kstep(t, 0, true, false, 0, false);     // last stage: its second k-step fetches nothing
+        kstep(t, 1, false, false, 0, false);
+    } else {
+        int t = 0;
+        for (; t + 4 < T; ++t) idle_stage(t, true, 8, true);
+        idle_stage(t, true, 8, false);
+        idle_stage(t + 1, true, 4, false);
+        idle_stage(t + 2, true, 0, false);
+    }
+#undef SGLK_FENCE
+
+    // ---- epilogue: one rounding to bf16, image in LDS, whole rows out ----------------------------------------------------
+    // image rows: 256 bf16 columns = 512 B (PLAIN / DOWN) or 128 bf16 columns = 256 B (GATE_UP)
+    __syncthreads();   // every wave is done reading the ring
+    constexpr int kCols = (MODE == MODE_GATE_UP) ? 128 : 256;
+    constexpr int kRowB = kCols * 2;
+    if (active) {
+        if (MODE == MODE_GATE_UP) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int r = wm * 128 + tt * 32 + r32;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 v;
+                    v.x = pack_bf16x2(silu_f32(acc[0][tt][rg * 4 + 0]) * acc[1][tt][rg * 4 + 0], silu_f32(acc[0][tt][rg * 4 + 1]) * acc[1][tt][rg * 4 + 1]);
+                    v.y = pack_bf16x2(silu_f32(acc[0][tt][rg * 4 + 2]) * acc[1][tt][rg * 4 + 2], silu_f32(acc[0][tt][rg * 4 + 3]) * acc[1][tt][rg * 4 + 3]);
+                    const int col = wn * 32 + rg * 8 + h * 4;            // 4 consecutive ic1 columns
+                    const int chunk = (col >> 3) ^ (r & 15);
+                    *reinterpret_cast<uint2*>(smem + r * kRowB + chunk * 16 + (col & 4) * 2) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int r = wm * 128 + tt * 32 + r32;
+                const float tw = (MODE == MODE_DOWN) ? bias_tab[r] : 1.f;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int col = wn * 64 + rt * 32 + rg * 8 + h * 4;
+                        float o4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i];
+                        if (MODE == MODE_PLAIN) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + col);
+                            o4[0] += b4.x; o4[1] += b4.y; o4[2] += b4.z; o4[3] += b4.w;
+                        }
+                        if (MODE == MODE_DOWN) { o4[0] *= tw; o4[1] *= tw; o4[2] *= tw; o4[3] *= tw; }
+                        uint2 v;
+                        v.x = pack_bf16x2(o4[0], o4[1]);
+                        v.y = pack_bf16x2(o4[2], o4[3]);
+                        const int chunk = (col >> 3) ^ (r & 15);
+                        *reinterpret_cast<uint2*>(smem + r * kRowB + chunk * 16 + (col & 4) * 2) = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int kChunksPerRow = kRowB / 16;          // 16 or 32
+    constexpr int kIters = kBM * kChunksPerRow / 512;  // 8 or 16
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+        const int idx = it * 512 + tid;
+        const int r = idx / kChunksPerRow;
+        const int pc = idx - r * kChunksPerRow;
+        const int lc = pc ^ (r & 15);                  // logical chunk: 8 bf16 columns
+        if (r < rows) {
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
+            const int64_t orow = (MODE == MODE_DOWN) ? (int64_t)slot_tab[r] : (int64_t)(pos0 + r);
+            *reinterpret_cast<uint4*>(p.out + orow * p.out_stride + ntile * kCols + lc * 8) = v;
+        }
+    }
+}
+
+}  // namespace gb16
+
+int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream) {
+    if (p.K < 128 || p.K % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_256: reduction length %d must be a multiple of 32 and >= 128", p.K);
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks <= 0) return SGLK_OK;
+    if (mode == MODE_GATE_UP) hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    else if (mode == MODE_DOWN) hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_PLAIN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
+    SGLK_CHECK_LAUNCH("gemm_bf16_256");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

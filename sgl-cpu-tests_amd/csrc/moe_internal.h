@@ -70,6 +70,27 @@ struct I8GemmParams {
 };
 int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 
+// ---- bf16 GEMM with VNNI-2 packed weights on the bf16 matrix cores (gemm_bf16_256.hip) ------------------------------------
+struct Bf16GemmParams {
+    const uint16_t* x;        // bf16 [rows][K], row stride x_stride BYTES (multiple of 16)
+    int64_t x_stride;
+    int64_t x_bytes;          // extent of x (< 4 GiB, buffer descriptor)
+    const uint8_t* w;         // packed bf16 [E][R/32][K/2][32][2]
+    int64_t w_bytes;          // bytes per expert = R * K * 2 (< 4 GiB)
+    const float* bias;        // PLAIN: [R] f32 or null
+    uint16_t* out;            // bf16: PLAIN [M][R]; GATE_UP ic1 [position][N]; DOWN ic2 [slot][R]
+    int64_t out_stride;       // elements
+    int M, K;                 // dense: rows of x; K = reduction length (elements)
+    int n_tiles;              // PLAIN / DOWN: R / 256; GATE_UP: N / 128
+    const int4* tile_info;    // grouped: m-tile table with tile_m = 256; null = dense
+    const int* num_tiles;
+    const int* sorted_slot;
+    int topk;
+    int n_half;               // GATE_UP: N
+    const float* topk_weights;   // DOWN
+};
+int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream);
+
 // ---- generic engine (gemm_generic.hip) ------------------------------------------------------------------------------
 constexpr int kGenericTileM = 64;
 enum { GG_GATE_UP = 0, GG_DOWN = 1, GG_PLAIN = 2 };

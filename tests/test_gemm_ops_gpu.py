@@ -220,6 +220,54 @@ def test_int8_mfma_gemm_is_exact(ops, shape):
     assert ref_pred(ogemm.int8_scaled_mm(Aq, As, Bq, Bs, bias).bfloat16(), out)
 
 
+@pytest.mark.parametrize("shape", [(192, 256, 128, False), (1000, 512, 1024, True), (300, 768, 2080, True), (2049, 1536, 2048, False)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_bf16_packed_linear_on_tuned_kernel(ops, shape):
+    """Large-M weight_packed_linear with VNNI-2 packed weights runs on csrc/gemm_bf16_256.hip; oracle: fp32 matmul of the
+    bf16 operands (+ bias) rounded once (/root/reference/test_gemm.py:15-21), reference predicate; also equal within
+    rounding noise to the row-major (generic engine) path."""
+    M, N, K, has_bias = shape
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, generator=g) / 8).bfloat16()
+    w = (torch.randn(N, K, generator=g) / 8).bfloat16()
+    bias = torch.randn(N, generator=g) if has_bias else None
+    ref = x.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    wp = ops.convert_weight_packed(w.cuda())
+    b = bias.cuda() if bias is not None else None
+    out = ops.weight_packed_linear(x.cuda(), wp, b, True)
+    assert ref_pred(ref, out)
+    assert rel_rms(out, ref) < 3e-3
+    plain = ops.weight_packed_linear(x.cuda(), w.cuda(), b, False)
+    assert rel_rms(out, plain) < 3e-3
+
+
+@pytest.mark.parametrize("shape", [(1024, 768, 2048, 16, 4), (1000, 128, 256, 4, 2), (3000, 384, 1024, 32, 8)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_bf16_on_tuned_kernel(ops, shape):
+    """Large-M packed bf16 fused_experts runs both grouped GEMMs on csrc/gemm_bf16_256.hip; oracle: the fp32 restatement
+    of /root/reference/test_moe.py:22-54 (oracle/moe.py), reference predicate; masked slots; run-to-run bit identity."""
+    M, N, K, E, topk = shape
+    g = torch.Generator().manual_seed(5000 + M)
+    a = (torch.randn(M, K, generator=g) / 10).bfloat16()
+    w1 = (torch.randn(E, 2 * N, K, generator=g) / 10).bfloat16()
+    w2 = (torch.randn(E, K, N, generator=g) / 10).bfloat16()
+    tw, ids = moe.softmax_topk(torch.randn(M, E, generator=g).bfloat16(), topk, True)
+    ids = ids.clone()
+    ids[::5, 0] = -1
+    ref = moe.fused_experts_f32(a, w1, w2, tw, ids)
+    w1p, w2p = ops.convert_weight_packed(w1.cuda()), ops.convert_weight_packed(w2.cuda())
+    args = (tw.cuda(), ids.cuda(), False, False, False, None, None, None, None, None)
+    out = ops.fused_experts_cpu(a.cuda(), w1p, w2p, *args, True)
+    assert rel_rms(out, ref) < 6e-3
+    assert ref_pred(ref, out) or rel_rms(out, ref) < 4e-3   # |out| reaches O(10) here: the absolute part of the predicate is tight
+    generic = ops.fused_experts_cpu(a.cuda(), w1.cuda(), w2.cuda(), *args, False)
+    assert rel_rms(out, generic) < 4e-3
+    again = ops.fused_experts_cpu(a.cuda(), w1p, w2p, *args, True)
+    assert torch.equal(out, again)
+
+
 def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):
     """Same fp8 fused_experts inputs through the tuned path and (forced) through the generic engine."""
     name, M, N, K, E, topk, bn, bk, masked, seed, full = recipes.MOE_FP8_CASES[1]

@@ -150,12 +150,14 @@ def bench_gemm():
         wi = torch.randint(-127, 127, (N, K), device="cuda", generator=g, dtype=torch.int8)
         sc = torch.randn(N // 128, K // 128, device="cuda", generator=g) * 1e-3
         wfp = ops.convert_weight_packed(wf)          # the reference benches prepacked weights (bench_gemm.py:64-69)
+        wbp = ops.convert_weight_packed(wb)
         wip = ops.convert_weight_packed(wi)
         si = torch.rand(N, device="cuda", generator=g) * 1e-2
         xq, xs = ops.per_token_quant_int8_cpu(x)
         flop = 2 * M * N * K
         for name, fn in (
-                ("weight_packed_linear_bf16", lambda i: ops.weight_packed_linear(x, wb, None, False)),
+                ("weight_packed_linear_bf16_packed", lambda i: ops.weight_packed_linear(x, wbp, None, True)),
+                ("weight_packed_linear_bf16_rowmajor", lambda i: ops.weight_packed_linear(x, wb, None, False)),
                 ("fp8_scaled_mm_packed", lambda i: ops.fp8_scaled_mm_cpu(x, wfp, sc, [128, 128], None, torch.bfloat16, True)),
                 ("fp8_scaled_mm_rowmajor", lambda i: ops.fp8_scaled_mm_cpu(x, wf, sc, [128, 128], None, torch.bfloat16, False)),
                 ("int8_scaled_mm_packed", lambda i: ops.int8_scaled_mm_cpu(xq, wip, xs, si, None, torch.bfloat16, True)),
