@@ -138,6 +138,19 @@ def bench_moe_int8():
         flop = M * topk * 6 * N * K
         emit(op="fused_experts_int8", M=M, ms=round(ms, 4), tops=round(flop / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3),
              roofline_frac=round(flop / ms / 1e9 / (2 * PEAK_BF16), 4), peak_tops=2 * PEAK_BF16, bound="mfma (int8, 2x bf16)")
+    del w1, w2
+    # bf16 experts (bench_moe.py:65-82), weights in the reference's VNNI-2 packed order
+    b1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
+    b2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 0.02).bfloat16())
+    for M in (1024, 4096, 16384):
+        a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        score = torch.softmax(torch.randn(M, E, device="cuda", generator=g).bfloat16(), dim=-1, dtype=torch.float32)
+        tw, ids = torch.topk(score, topk)
+        ids = ids.to(torch.int32)
+        ms = timed(lambda i: ops.fused_experts_cpu(a, b1, b2, tw, ids, False, False, False, None, None, None, None, None, True), 20)
+        flop = M * topk * 6 * N * K
+        emit(op="fused_experts_bf16", M=M, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3),
+             roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
 
 
 def bench_gemm():
