@@ -13,6 +13,8 @@
 //     stride 128 B: four conflict-free ds_read_b32 with immediate offsets -- the k order inside the lane is natural,
 //     so the activation fragments are read exactly as in the other kernels.
 // fp32 accumulation, one rounding to bf16 (GATE_UP: after SiLU*mul; DOWN: after the routing weight).
+#include <stdlib.h>
+
 #include "sglk_common.h"
 #include "moe_internal.h"
 
@@ -335,12 +337,193 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
     }
 }
 
+
+// ---- experimental variant (SGLK_BF16_W4=1, dense only): FOUR waves, one per SIMD, each owning 128 weight rows x 128
+// tokens (4 x 4 MFMA tiles, 256 accumulator registers).  Every operand fragment is then used by four MFMAs instead of
+// two / four, so the LDS read volume per stage drops from 160 KiB to 96 KiB (the quantity the clock reacts to,
+// DESIGN.md 4.1); the price is a single instruction stream per SIMD with no partner wave to cover its stalls.
+__global__ __launch_bounds__(256) void gemm_bf16_256w4_kernel(const Bf16GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wm = wave >> 1;
+
+    const int mtiles = (p.M + kBM - 1) / kBM;
+    const int live = mtiles * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int L = xcd_remap(blockIdx.x, live);
+    const int mtile = L / p.n_tiles;
+    const int ntile = L - mtile * p.n_tiles;
+    const int pos0 = mtile * kBM;
+    const int rows = (p.M - pos0 < kBM) ? p.M - pos0 : kBM;
+    const int T = p.K >> 5;
+
+    float* bias_tab = reinterpret_cast<float*>(smem + kTabOff);
+    const float my_b = p.bias ? p.bias[ntile * 256 + tid] : 0.f;
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)p.w_bytes, 0x00020000);
+    const int kpairs = p.K >> 1;
+    unsigned xsrc[4], wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 16 + (lane >> 2);
+        const int rr = r < rows ? r : 0;
+        xsrc[i] = (unsigned)((int64_t)(pos0 + rr) * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+        const int piece = wave * 4 + i;                     // W piece = row block piece>>1, half piece&1
+        wsrc[i] = (unsigned)((ntile * 8 + (piece >> 1)) * kpairs) * 128u + (unsigned)(piece & 1) * 1024u + lane * 16;
+    }
+    auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // i = 0..3: X rows; 4..7: W
+        unsigned char* sx = smem + buf * kStage;
+        if (i < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sx + (wave * 4 + i) * 1024), 16, xsrc[i], kt * 64, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(sx + kStageX + (wave * 4 + i - 4) * 1024), 16,
+                                                     wsrc[i - 4], kt * 2048, 0, 0);
+    };
+
+    const int h = lane >> 5, r32 = lane & 31;
+    const int wbase = wn * 4 * 2048 + h * 512 + r32 * 4;     // + rt * 2048 + ks * 1024 + j * 128
+    const int xrow0 = wm * 128 + r32;
+    auto xoff = [&](int tt, int ks) __attribute__((always_inline)) {
+        const int row = xrow0 + tt * 32;
+        return row * 64 + (((2 * ks + h) ^ ((row >> 2) & 3)) << 4);
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0.f;
+
+#pragma unroll
+    for (int st = 0; st < kRing; ++st)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_piece(st, st, i);
+    bias_tab[tid] = my_b;
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // T >= 4: stage 0 of 4 x 8 pieces landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
+    i32x4v wf[2][4], xf[2][4];
+    auto ld_w = [&](int par, int rt, int fbuf, int ks) __attribute__((always_inline)) {
+        const unsigned char* wp = smem + fbuf * kStage + kStageX + wbase + rt * 2048 + ks * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[par][rt][j] = *reinterpret_cast<const int*>(wp + j * 128);
+    };
+    auto ld_x = [&](int par, int tt, int fbuf, int ks) __attribute__((always_inline)) {
+        xf[par][tt] = *reinterpret_cast<const i32x4v*>(smem + fbuf * kStage + xoff(tt, ks));
+    };
+    auto mma = [&](int par, int s2) __attribute__((always_inline)) {
+        const int rt = s2 >> 2, tt = s2 & 3;
+        acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[par][rt]),
+                                                              __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
+    };
+    int buf = 0;
+    // 16 MFMA slots per k-step; slot s < 4 carries W row tile s and X token tile s of the next k-step; in k-step 1 the even
+    // slots from 2 on (and slot 15) carry the eight DMA pieces of the refill
+    auto kstep = [&](int t, int ks, bool fetch, bool sync, int wait_pieces, bool refill) __attribute__((always_inline)) {
+        const int par = ks, npar = ks ^ 1;
+        const int nbuf = (buf + 1) & (kRing - 1);
+        const int fbuf = ks ? nbuf : buf;
+        const int fks = ks ^ 1;
+        mma(par, 0);
+        SGLK_FENCE();
+        if (sync) {
+            mma(par, 1);
+            SGLK_FENCE();
+            if (wait_pieces == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (wait_pieces == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (fetch) { ld_w(npar, 0, fbuf, fks); ld_x(npar, 0, fbuf, fks); ld_w(npar, 1, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            SGLK_FENCE();
+        } else {
+            if (fetch) { ld_w(npar, 0, fbuf, fks); ld_x(npar, 0, fbuf, fks); }
+            SGLK_FENCE();
+            mma(par, 1);
+            SGLK_FENCE();
+            if (fetch) { ld_w(npar, 1, fbuf, fks); ld_x(npar, 1, fbuf, fks); }
+            SGLK_FENCE();
+        }
+#pragma unroll
+        for (int s2 = 2; s2 < 16; ++s2) {
+            mma(par, s2);
+            SGLK_FENCE();
+            if (fetch && s2 < 4) { ld_w(npar, s2, fbuf, fks); ld_x(npar, s2, fbuf, fks); }
+            if (refill && ((s2 & 1) == 0 || s2 == 15)) issue_piece(t + 4, buf, s2 == 15 ? 7 : (s2 - 2) >> 1);
+            SGLK_FENCE();
+        }
+    };
+    // the buffer of stage t is free after the sync point in its k-step 1, whose remaining 14 slots carry all eight pieces
+    // of stage t+4
+    ld_w(0, 0, 0, 0); ld_w(0, 1, 0, 0); ld_w(0, 2, 0, 0); ld_w(0, 3, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) ld_x(0, tt, 0, 0);
+    SGLK_FENCE();
+    int t = 0;
+    for (; t + 4 < T; ++t) {
+        kstep(t, 0, true, false, 0, false);
+        kstep(t, 1, true, true, 16, true);
+        buf = (buf + 1) & (kRing - 1);
+    }
+    // (simplification for the experiment: the drain issues nothing and waits for everything)
+    for (; t + 1 < T; ++t) {
+        kstep(t, 0, true, false, 0, false);
+        kstep(t, 1, true, true, 0, false);
+        buf = (buf + 1) & (kRing - 1);
+    }
+    kstep(t, 0, true, false, 0, false);
+    kstep(t, 1, false, false, 0, false);
+#undef SGLK_FENCE
+
+    __syncthreads();
+    constexpr int kRowB = 512;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int r = wm * 128 + tt * 32 + r32;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int col = wn * 128 + rt * 32 + rg * 8 + h * 4;
+                const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + col);
+                uint2 v;
+                v.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] + b4.x, acc[rt][tt][rg * 4 + 1] + b4.y);
+                v.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] + b4.z, acc[rt][tt][rg * 4 + 3] + b4.w);
+                const int chunk = (col >> 3) ^ (r & 15);
+                *reinterpret_cast<uint2*>(smem + r * kRowB + chunk * 16 + (col & 4) * 2) = v;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 32; ++it) {
+        const int idx = it * 256 + tid;
+        const int r = idx >> 5, pc = idx & 31;
+        const int lc = pc ^ (r & 15);
+        if (r < rows) {
+            const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
+            *reinterpret_cast<uint4*>(p.out + (int64_t)(pos0 + r) * p.out_stride + ntile * 256 + lc * 8) = v;
+        }
+    }
+}
+
 }  // namespace gb16
 
 int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream) {
     if (p.K < 128 || p.K % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_256: reduction length %d must be a multiple of 32 and >= 128", p.K);
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks <= 0) return SGLK_OK;
+    static const bool w4 = getenv("SGLK_BF16_W4") != nullptr;
+    if (w4 && mode == MODE_PLAIN && !p.tile_info) {
+        hipLaunchKernelGGL(gb16::gemm_bf16_256w4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        SGLK_CHECK_LAUNCH("gemm_bf16_256w4");
+        return SGLK_OK;
+    }
     if (mode == MODE_GATE_UP) hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     else if (mode == MODE_DOWN) hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(gb16::gemm_bf16_256_kernel<MODE_PLAIN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
