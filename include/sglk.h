@@ -176,6 +176,26 @@ int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
 int sglk_per_token_quant_int8(const void* x, int64_t x_stride, void* q, int64_t q_stride, float* scale,
                               int64_t rows, int32_t cols, void* stream);
 
+/* the same with an explicit amax floor (the MLA projection's oracle uses 1e-7, /root/reference/test_absorb.py:33-40) */
+int sglk_per_token_quant_int8_floor(const void* x, int64_t x_stride, void* q, int64_t q_stride, float* scale,
+                                    int64_t rows, int32_t cols, float floor, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pieces of qkv_proj_with_rope (/root/reference/test_absorb.py:133-147; oracle native_torch :65-87) that are neither a
+ * GEMM nor an RMSNorm; the Python layer composes the operator from these, sglk_scaled_mm and sglk_rmsnorm.
+ *   bmm_heads  out[b][h][oc] = sum_ic x[b][h][ic] * w[h][oc][ic]   (bf16, fp32 accumulation; w [H][OC][IC] row-major or
+ *              packed per head in convert_weight_packed's bf16 order)         torch.bmm(q_nope^T, w_kc), test_absorb.py:73
+ *   rope_gptj  out = x * cos + rotate_gptj(x) * sin on the rotary slices of q [B][H][d] and k [B][d]; cache row =
+ *              [cos(d/2) | sin(d/2)] indexed by positions                      rotary_emb, test_absorb.py:27-31,49-63
+ * strides in elements.
+ * --------------------------------------------------------------------------------------------------------- */
+int sglk_bmm_heads(const void* x, int64_t x_stride_b, int64_t x_stride_h, const void* w, int32_t packed, void* out,
+                   int64_t out_stride_b, int64_t out_stride_h, int32_t B, int32_t H, int32_t OC, int32_t IC, void* stream);
+int sglk_rope_gptj(const void* q_pe, int64_t q_stride_b, int64_t q_stride_h, const void* k_pe, int64_t k_stride_b,
+                   const void* positions, int32_t positions_is64, const void* cos_sin_cache, int64_t cache_stride,
+                   void* q_out, int64_t q_out_stride_b, int64_t q_out_stride_h, void* k_out, int64_t k_out_stride_b,
+                   int32_t B, int32_t H, int32_t rotary_dim, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Row kernels (bf16 or fp16 I/O selected by is_f16; strides in elements)
  *   silu_and_mul        out[r][c] = silu(x[r][c]) * x[r][d+c]      /root/reference/test_activation.py:14-28,

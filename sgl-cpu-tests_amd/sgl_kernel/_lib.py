@@ -108,6 +108,16 @@ _SIGNATURES = {
     "sglk_scaled_mm": (ctypes.c_int, [ctypes.POINTER(ScaledMmArgs), ctypes.c_void_p]),
     "sglk_per_token_quant_int8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_per_token_quant_int8_floor": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
+                                                        ctypes.c_void_p]),
+    "sglk_bmm_heads": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int32,
+                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_rope_gptj": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_silu_and_mul": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_rmsnorm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,

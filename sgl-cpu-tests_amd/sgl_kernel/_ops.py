@@ -397,6 +397,89 @@ _impl("int8_scaled_mm_with_quant", int8_scaled_mm_with_quant)
 
 
 # ------------------------------------------------------------------------------------------------------
+# qkv_proj_with_rope: MLA "absorbed" q/k/v projection (/root/reference/test_absorb.py:133-147,184-186).  Host logic
+# only: the operator is the reference's sequence of GEMM / RMSNorm / per-head product / RoPE, each step one C-ABI call
+# (sglk_scaled_mm, sglk_rmsnorm, sglk_bmm_heads, sglk_rope_gptj), same op order and rounding points as the oracle
+# (native_torch / native_torch_int8, test_absorb.py:65-109).
+_DEF.define("qkv_proj_with_rope(Tensor hidden_states, Tensor q_a_proj_weight, Tensor q_b_proj_weight, "
+            "Tensor kv_a_proj_weight, Tensor w_kc, Tensor q_a_layernorm_weight, Tensor kv_a_layernorm_weight, "
+            "Tensor positions, Tensor cos_sin_cache, float eps, bool use_int8_w8a8, bool use_fp8_w8a16, "
+            "Tensor? q_a_proj_scale, Tensor? q_b_proj_scale, Tensor? kv_a_proj_scale, bool is_vnni, "
+            "int[]? block_size) -> (Tensor, Tensor, Tensor)")
+
+
+def qkv_proj_with_rope(hidden_states, q_a_proj_weight, q_b_proj_weight, kv_a_proj_weight, w_kc, q_a_layernorm_weight,
+                       kv_a_layernorm_weight, positions, cos_sin_cache, eps, use_int8_w8a8, use_fp8_w8a16,
+                       q_a_proj_scale, q_b_proj_scale, kv_a_proj_scale, is_vnni, block_size):
+    hs = hidden_states
+    if hs.dim() != 2 or hs.dtype != torch.bfloat16:
+        raise RuntimeError("qkv_proj_with_rope: hidden_states must be a 2-D bfloat16 tensor")
+    if w_kc.dim() != 3 or w_kc.dtype != torch.bfloat16:
+        raise RuntimeError("qkv_proj_with_rope: w_kc must be [num_heads, kv_lora_rank, qk_nope_head_dim] bfloat16")
+    if use_int8_w8a8 and use_fp8_w8a16:
+        raise RuntimeError("qkv_proj_with_rope: use_int8_w8a8 and use_fp8_w8a16 are mutually exclusive")
+    B = hs.shape[0]
+    H, R, nope = w_kc.shape
+    if q_b_proj_weight.shape[0] % H != 0:
+        raise RuntimeError("qkv_proj_with_rope: q_b_proj rows must be num_heads * qk_head_dim")
+    qk_head = q_b_proj_weight.shape[0] // H
+    rope_dim = qk_head - nope
+    if rope_dim <= 0 or rope_dim % 2 or kv_a_proj_weight.shape[0] != R + rope_dim or cos_sin_cache.shape[-1] != rope_dim:
+        raise RuntimeError("qkv_proj_with_rope: inconsistent head dims")
+    if cos_sin_cache.dtype != torch.bfloat16 or positions.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError("qkv_proj_with_rope: cos_sin_cache must be bfloat16 and positions int64/int32")
+    L = _lib.lib()
+    st = _stream(hs)
+
+    if use_int8_w8a8:
+        if q_a_proj_scale is None or q_b_proj_scale is None or kv_a_proj_scale is None:
+            raise RuntimeError("qkv_proj_with_rope: int8 needs the three weight scales")
+
+        def lin(x, w, s):    # per-token quantisation with the oracle's 1e-7 floor, then W8A8 GEMM, bf16 out
+            x = x if x.stride(-1) == 1 else x.contiguous()
+            q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+            xs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+            _lib.check(L.sglk_per_token_quant_int8_floor(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(xs), x.shape[0],
+                                                         x.shape[1], 1e-7, st), "qkv_proj_with_rope(quant)")
+            return _scaled_mm(q, w, s.reshape(-1), None, torch.bfloat16, is_vnni, None, x_scale=xs)
+    elif use_fp8_w8a16:
+        if block_size is None or len(block_size) != 2:
+            raise RuntimeError("qkv_proj_with_rope: fp8 needs block_size [block_n, block_k]")
+
+        def lin(x, w, s):
+            return _scaled_mm(x, w, s, None, torch.bfloat16, is_vnni, block_size)
+    else:
+        def lin(x, w, s):
+            return _scaled_mm(x, w, None, None, torch.bfloat16, is_vnni, None)
+
+    q = lin(hs, q_a_proj_weight, q_a_proj_scale)
+    qn = torch.empty_like(q)
+    rmsnorm_cpu(qn, q, q_a_layernorm_weight, eps)
+    q = lin(qn, q_b_proj_weight, q_b_proj_scale).view(B, H, qk_head)
+    latent = lin(hs, kv_a_proj_weight, kv_a_proj_scale)                       # [B, R + rope]
+
+    q_input = torch.empty(B, H, R + rope_dim, dtype=torch.bfloat16, device=hs.device)
+    k_input = torch.empty(B, 1, R + rope_dim, dtype=torch.bfloat16, device=hs.device)
+    v_input = torch.empty(B, 1, R, dtype=torch.bfloat16, device=hs.device)
+    wk = w_kc if w_kc.is_contiguous() else w_kc.contiguous()
+    _lib.check(L.sglk_bmm_heads(_ptr(q), q.stride(0), q.stride(1), _ptr(wk), 1 if is_vnni else 0, _ptr(q_input),
+                                q_input.stride(0), q_input.stride(1), B, H, R, nope, st), "qkv_proj_with_rope(w_kc)")
+    rmsnorm_cpu(v_input.view(B, R), latent[:, :R], kv_a_layernorm_weight, eps)
+    k_input[:, 0, :R].copy_(v_input.view(B, R))
+    pos = positions if positions.is_contiguous() else positions.contiguous()
+    cache = cos_sin_cache if cos_sin_cache.stride(-1) == 1 else cos_sin_cache.contiguous()
+    q_pe, k_pe = q[:, :, nope:], latent[:, R:]
+    qo, ko = q_input[:, :, R:], k_input[:, 0, R:]
+    _lib.check(L.sglk_rope_gptj(_ptr(q_pe), q_pe.stride(0), q_pe.stride(1), _ptr(k_pe), k_pe.stride(0), _ptr(pos),
+                                1 if pos.dtype == torch.int64 else 0, _ptr(cache), cache.stride(0), _ptr(qo), qo.stride(0),
+                                qo.stride(1), _ptr(ko), ko.stride(0), B, H, rope_dim, st), "qkv_proj_with_rope(rope)")
+    return q_input, k_input, v_input
+
+
+_impl("qkv_proj_with_rope", qkv_proj_with_rope)
+
+
+# ------------------------------------------------------------------------------------------------------
 # silu_and_mul_cpu: returning form /root/reference/bench_silu_and_mul.py:31; out-param form
 #                   sgl_kernel.ops._kernels.silu_and_mul_cpu(out, x) /root/reference/test_activation.py:25
 # rmsnorm_cpu / fused_add_rmsnorm_cpu: out-param / in-place, /root/reference/test_norm.py:44,56

@@ -24,6 +24,7 @@ Families -> reference oracle used
                                                /root/reference/test_gemm_fp8.py:22-49
   attn      _run_sdpa_forward_extend/decode    /root/reference/test_extend.py:10-76,
                                                /root/reference/test_mla.py:12-66
+  absorb    native_torch / native_torch_int8   /root/reference/test_absorb.py:20-109
 """
 import ast
 import hashlib
@@ -267,8 +268,37 @@ def gen_attn():
                   input_sha256=checksum(inp["q"], inp["k_buffer"], inp["key"], inp["loc"])))
 
 
+def gen_absorb():
+    """qkv_proj_with_rope: native_torch / native_torch_int8 of /root/reference/test_absorb.py:65-109 (and their helpers
+    :20-63), run with the file's own module constants (:10-17)."""
+    d = recipes.ABSORB_DIMS
+    consts = dict(kv_lora_rank=d["kv_lora_rank"], qk_head_dim=d["qk_nope_head_dim"] + d["qk_rope_head_dim"],
+                  qk_nope_head_dim=d["qk_nope_head_dim"], qk_rope_head_dim=d["qk_rope_head_dim"],
+                  rotary_dim=d["qk_rope_head_dim"], num_heads=d["num_heads"], q_lora_rank=d["q_lora_rank"])
+    ns = lift("test_absorb.py", ["layernorm", "_rotate_gptj", "per_token_quant_int8", "native_w8a8_per_token_matmul",
+                                 "rotary_emb", "native_torch", "native_torch_int8"], consts)
+    for name, B, hidden, seed in recipes.ABSORB_CASES:
+        inp = recipes.absorb_inputs(B, hidden, seed)
+        bf = torch.bfloat16
+        q_in = torch.zeros(B, d["num_heads"], d["kv_lora_rank"] + d["qk_rope_head_dim"], dtype=bf)
+        q, k, v = ns["native_torch"](q_in, inp["hidden_states"], inp["q_a_proj_weight"], inp["norm_weight1"],
+                                     inp["q_b_proj_weight"], inp["w_kc"].transpose(1, 2), inp["kv_a_proj_weight"],
+                                     inp["norm_weight2"], inp["pos"], inp["cos_sin_cache"])
+        w1q, w1s = ns["per_token_quant_int8"](inp["q_a_proj_weight"])
+        w2q, w2s = ns["per_token_quant_int8"](inp["q_b_proj_weight"])
+        w3q, w3s = ns["per_token_quant_int8"](inp["kv_a_proj_weight"])
+        q_in8 = torch.zeros_like(q_in)
+        q8, k8, v8 = ns["native_torch_int8"](q_in8, inp["hidden_states"], w1q, w1s, inp["norm_weight1"], w2q, w2s,
+                                             inp["w_kc"].transpose(1, 2), w3q, w3s, inp["norm_weight2"], inp["pos"],
+                                             inp["cos_sin_cache"])
+        save("absorb_" + name, {"q": q.clone(), "k": k.clone(), "v": v.clone(), "q_int8": q8.clone(), "k_int8": k8.clone(),
+                                "v_int8": v8.clone()},
+             dict(B=B, hidden=hidden, seed=seed, input_sha256=checksum(inp["hidden_states"], inp["q_a_proj_weight"], inp["w_kc"])))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn}
+            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb}
+
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(FAMILIES)

@@ -318,3 +318,33 @@ def decode_inputs(B, H_Q, H_KV, D, DV, seq_len, v_alias, seed):
     req_to_token = torch.arange(total).reshape(B, seq_len).to(torch.int64)
     return dict(q=q, k_buffer=k_buffer, v_buffer=v_buffer, key=key, value=value, loc=loc, req_to_token=req_to_token,
                 b_req_idx=torch.arange(B, dtype=torch.int64), b_seq_len=torch.full((B,), seq_len, dtype=torch.int64))
+
+
+# name, B, hidden, seed     qkv_proj_with_rope (/root/reference/test_absorb.py:111-131,196; DeepSeek-style MLA dims :11-17)
+ABSORB_DIMS = dict(kv_lora_rank=512, qk_nope_head_dim=128, qk_rope_head_dim=64, num_heads=22, q_lora_rank=1536)
+ABSORB_CASES = [
+    ("b3_h7168", 3, 7168, 9111),
+    ("b1_h2048", 1, 2048, 9112),
+    ("b17_h1024", 17, 1024, 9113),
+]
+
+
+def absorb_inputs(B, hidden, seed):
+    """/root/reference/test_absorb.py:113-131.  int8 variants of the three projections are quantised per output row
+    like the reference does (:163-165)."""
+    d = ABSORB_DIMS
+    g = _gen(seed)
+    bf = torch.bfloat16
+    H, qk_head = d["num_heads"], d["qk_nope_head_dim"] + d["qk_rope_head_dim"]
+    out = dict(
+        hidden_states=(torch.randn(B, hidden, generator=g) / hidden).to(bf),
+        q_a_proj_weight=(torch.randn(d["q_lora_rank"], hidden, generator=g) * 0.1).to(bf),
+        norm_weight1=torch.randn(d["q_lora_rank"], generator=g).to(bf),
+        q_b_proj_weight=(torch.randn(H * qk_head, d["q_lora_rank"], generator=g) * 0.1).to(bf),
+        w_kc=(torch.randn(H, d["kv_lora_rank"], d["qk_nope_head_dim"], generator=g) * 0.1).to(bf),
+        kv_a_proj_weight=(torch.randn(d["kv_lora_rank"] + d["qk_rope_head_dim"], hidden, generator=g) * 0.1).to(bf),
+        norm_weight2=torch.randn(d["kv_lora_rank"], generator=g).to(bf),
+        pos=torch.randint(10, 100, (B,), generator=g),
+        cos_sin_cache=torch.randn(100, d["qk_rope_head_dim"], generator=g).to(bf),
+    )
+    return out

@@ -257,3 +257,21 @@ def test_oracle_decode_attention(case):
                                  inp["b_seq_len"], 1.0 / D ** 0.5)
     assert torch.allclose(out.bfloat16().float(), g["ref_out"].float(), atol=3e-2)      # test_mla.py:173
     assert torch.equal(kb[inp["loc"]], inp["key"])
+
+
+# ---- qkv_proj_with_rope (oracle/absorb.py vs the reference's native_torch / native_torch_int8) --------------------------
+@pytest.mark.parametrize("case", recipes.ABSORB_CASES, ids=lambda c: c[0])
+def test_absorb_oracle_matches_reference_oracle(case):
+    from oracle import absorb
+    from oracle.gemm import quant_int8_rowwise
+    name, B, hidden, seed = case
+    g, _ = load_golden("absorb_" + name)
+    inp = recipes.absorb_inputs(B, hidden, seed)
+    common = (inp["w_kc"], inp["norm_weight1"], inp["norm_weight2"], inp["pos"], inp["cos_sin_cache"])
+    q, k, v = absorb.qkv_proj_with_rope(inp["hidden_states"], inp["q_a_proj_weight"], inp["q_b_proj_weight"],
+                                        inp["kv_a_proj_weight"], *common)
+    assert torch.equal(q, g["q"]) and torch.equal(k, g["k"]) and torch.equal(v, g["v"])
+    w = [quant_int8_rowwise(inp[n], floor=1e-7) for n in ("q_a_proj_weight", "q_b_proj_weight", "kv_a_proj_weight")]
+    q8, k8, v8 = absorb.qkv_proj_with_rope(inp["hidden_states"], w[0][0], w[1][0], w[2][0], *common,
+                                           scales=(w[0][1], w[1][1], w[2][1]))
+    assert torch.equal(q8, g["q_int8"]) and torch.equal(k8, g["k_int8"]) and torch.equal(v8, g["v_int8"])

@@ -2,7 +2,7 @@
 """Secondary measurements (not the driver's bench.py): the M sweep of fp8 fused_experts and the other
 operators of SURVEY.md §8 at the shapes the reference benches, each against the roofline that bounds it.
 
-    python tools/bench_ops.py [moe|moe_literal|moe_int8|gemm|attn|rows|all] > gpurun_out/bench_ops.json
+    python tools/bench_ops.py [moe|moe_literal|moe_int8|gemm|attn|absorb|rows|all] > gpurun_out/bench_ops.json
 
 Prints one JSON object per line.  HIP-event timing on the current stream, warm-up, rotating clones where the working
 set would otherwise sit in the 256 MiB Infinity Cache.
@@ -220,6 +220,28 @@ def bench_attn():
              gbps=round(byts / ms / 1e6, 1), roofline_frac=round(byts / ms / 1e6 / PEAK_HBM, 4), bound="hbm")
 
 
+def bench_absorb():
+    """qkv_proj_with_rope (/root/reference/test_absorb.py) at decode sizes: HBM-bound on the projection weights."""
+    H, R, nope, rope, qlr, hidden = 22, 512, 128, 64, 1536, 7168
+    g = torch.Generator(device="cuda").manual_seed(8)
+    bf = torch.bfloat16
+    qa = ops.convert_weight_packed((torch.randn(qlr, hidden, device="cuda", generator=g) * 0.1).to(bf))
+    qb = ops.convert_weight_packed((torch.randn(H * (nope + rope), qlr, device="cuda", generator=g) * 0.1).to(bf))
+    kva = ops.convert_weight_packed((torch.randn(R + rope, hidden, device="cuda", generator=g) * 0.1).to(bf))
+    wkc = ops.convert_weight_packed((torch.randn(H, R, nope, device="cuda", generator=g) * 0.1).to(bf))
+    n1 = torch.randn(qlr, device="cuda", generator=g).to(bf)
+    n2 = torch.randn(R, device="cuda", generator=g).to(bf)
+    cache = torch.randn(4096, rope, device="cuda", generator=g).to(bf)
+    wbytes = 2 * (qlr * hidden + H * (nope + rope) * qlr + (R + rope) * hidden + H * R * nope)
+    for B in (1, 16, 128):
+        hs = (torch.randn(B, hidden, device="cuda", generator=g) / hidden).to(bf)
+        pos = torch.randint(0, 4096, (B,), device="cuda", generator=g)
+        ms = timed(lambda i: ops.qkv_proj_with_rope(hs, qa, qb, kva, wkc, n1, n2, pos, cache, 1e-6, False, False, None, None,
+                                                    None, True, None), 20)
+        emit(op="qkv_proj_with_rope_bf16", B=B, hidden=hidden, ms=round(ms, 4), gbps=round(wbytes / ms / 1e6, 1),
+             roofline_frac=round(wbytes / ms / 1e6 / PEAK_HBM, 4), bound="hbm (weights)")
+
+
 def bench_rows():
     g = torch.Generator(device="cuda").manual_seed(4)
     for rows, two_d in ((128, 22016), (1000, 18432 * 2), (17, 36864)):
@@ -247,7 +269,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "attn": bench_attn, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
