@@ -8,7 +8,7 @@ using namespace sglk;
 namespace {
 
 struct DenseWs {
-    size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, total;
+    size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, partial, total;
 };
 
 // the tuned 256-token fp8 kernel (moe_gemm_fp8w_256x.hip) takes a dense [M][C] x [R][C]^T when this holds
@@ -56,6 +56,10 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
             w.ic1q = take((size_t)M * N);
             w.ic1s = take((size_t)M * 4);
         }
+    }
+    if (!need_ic1) {   // plain dense GEMM: fp32 partials of the split-K form (small M)
+        const int ks = generic_ksplit(M, N, K);
+        if (ks > 1) w.partial = take((size_t)ks * M * N * 4);
     }
     w.total = off;
     return w;
@@ -338,5 +342,15 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     g.out_type = a->out_type;
     g.out_stride = a->out_stride;
     g.bias = a->bias;
+    g.ksplit = generic_ksplit(M, N, K);
+    if (g.ksplit > 1) {
+        const int stages = (int)ceil_div(K, 64);
+        int per = (int)ceil_div(stages, g.ksplit);
+        per += per & 1;                                   // whole fp8 K blocks
+        g.split_stages = per;
+        g.ksplit = (int)ceil_div(stages, per);
+        g.split_rows = M;
+        g.partial = (float*)(ws + w.partial);
+    }
     return launch_gemm_generic(GG_PLAIN, g, tiles, s);
 }

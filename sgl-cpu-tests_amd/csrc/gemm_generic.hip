@@ -94,9 +94,12 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const int live = p.num_tiles[0] * p.n_tiles;
-    if ((int)blockIdx.x >= live) return;
-    const int mtile = blockIdx.x / p.n_tiles;
-    const int ntile = blockIdx.x - mtile * p.n_tiles;
+    const bool split = (MODE == GG_PLAIN) && p.ksplit > 1;
+    const int ksr = split ? (int)(blockIdx.x % (unsigned)p.ksplit) : 0;            // reduction range of this workgroup
+    const int bid = split ? (int)(blockIdx.x / (unsigned)p.ksplit) : (int)blockIdx.x;
+    if (bid >= live) return;
+    const int mtile = bid / p.n_tiles;
+    const int ntile = bid - mtile * p.n_tiles;
     const int4 ti = p.tile_info[mtile];
     const int e = ti.x, pos0 = ti.y, rows = ti.z;
 
@@ -167,8 +170,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
         srow[nt] = (WTYPE == SGLK_W_FP8_E4M3 && wr >= 0) ? wr / p.block_n : 0;
     }
 
-    const int stages = (C + kBK - 1) / kBK;
-    for (int kt = 0; kt < stages; ++kt) {
+    const int stages_all = (C + kBK - 1) / kBK;
+    const int kt0 = split ? ksr * p.split_stages : 0;                               // split_stages is even (fp8 K blocks)
+    const int stages = split ? (kt0 + p.split_stages < stages_all ? kt0 + p.split_stages : stages_all) : stages_all;
+    for (int kt = kt0; kt < stages; ++kt) {
         uint4 xv[2], wv[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -242,6 +247,20 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
             }
     } else {
         const float tw = (MODE == GG_DOWN) ? p.topk_weights[slot] : 1.f;
+        if (split) {   // fp32 partial of this reduction range; bias / addend / cast happen in the reduce launch
+            float* prow = p.partial + ((int64_t)ksr * p.split_rows + orow) * p.n_out;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = col0 + nt * 16 + q4 + j;
+                    if (c >= p.n_out) continue;
+                    float v = acc[nt][j];
+                    if (WTYPE == SGLK_W_INT8) v = xs * v * wcs[c];
+                    prow[c] = v;
+                }
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -257,7 +276,38 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
     }
 }
 
+// out[r][c] = cast(sum over ranges (ascending) of partial[range][r][c] + bias[c] + addend[r][c] * scale)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GenericGemmParams p, int rows) {
+    const int64_t total = (int64_t)rows * p.n_out;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / p.n_out;
+        const int c = (int)(i - r * p.n_out);
+        float v = 0.f;
+        for (int k = 0; k < p.ksplit; ++k) v += p.partial[((int64_t)k * p.split_rows + r) * p.n_out + c];
+        if (p.bias) v += p.bias[c];
+        if (p.addend) v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.addend)[r * p.addend_stride + c]) * p.addend_scale;
+        if (p.out_type == SGLK_OUT_F32) reinterpret_cast<float*>(p.out)[r * p.out_stride + c] = v;
+        else if (p.out_type == SGLK_OUT_F16) reinterpret_cast<_Float16*>(p.out)[r * p.out_stride + c] = (_Float16)v;
+        else reinterpret_cast<unsigned short*>(p.out)[r * p.out_stride + c] = f32_to_bf16_bits(v);
+    }
+}
+
 }  // namespace gg
+
+// Split-K plan: small-M dense GEMMs put only ceil(M/64) * ceil(N/64) workgroups on 256 CUs and each walks the whole
+// reduction with one synchronous load per stage; cutting K lifts the number of workgroups to ~512.  Ranges are whole
+// pairs of 64-deep stages (fp8 K blocks) and at least four stages long; the fp32 partials are bounded to 64 MiB.
+int generic_ksplit(int M, int N, int K) {
+    if (M <= 0 || M > 256) return 1;
+    const int64_t tiles = ceil_div(M, kGenericTileM) * ceil_div(N, 64);
+    const int stages = (int)ceil_div(K, 64);
+    if (tiles >= 256 || stages < 8) return 1;
+    int ks = (int)(512 / tiles);
+    if (ks > stages / 4) ks = stages / 4;
+    if (ks > 32) ks = 32;
+    while (ks > 1 && (int64_t)ks * M * N * 4 > (64ll << 20)) --ks;
+    return ks < 2 ? 1 : ks;
+}
 
 // m-tile table of a dense [M] x ... problem: one "expert", rows in natural order
 __global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots) {
@@ -282,7 +332,10 @@ int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, int* 
 }
 
 int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream) {
-    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    const bool split = mode == GG_PLAIN && p.ksplit > 1;
+    if (split) SGLK_REQUIRE(p.partial && p.split_stages > 0 && p.split_stages % 2 == 0 && !p.scatter && p.gather == GG_GATHER_NONE,
+                            SGLK_ERR_INVALID, "gemm_generic: bad split-K parameters");
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles * (split ? p.ksplit : 1);
     if (blocks == 0) return SGLK_OK;
     const dim3 grid((unsigned)blocks), block(256);
 #define GG_LAUNCH(WT, XT, MD) hipLaunchKernelGGL((gg::gemm_generic_kernel<WT, XT, MD>), grid, block, 0, stream, p)
@@ -299,6 +352,13 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
 #undef GG_MODES
 #undef GG_LAUNCH
     SGLK_CHECK_LAUNCH("gemm_generic");
+    if (split) {
+        const int64_t total = (int64_t)p.split_rows * p.n_out;
+        int64_t rb = ceil_div(total, 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(gg::splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, p.split_rows);
+        SGLK_CHECK_LAUNCH("gemm_generic(split-K reduce)");
+    }
     return SGLK_OK;
 }
 

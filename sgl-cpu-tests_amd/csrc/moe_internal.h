@@ -125,7 +125,15 @@ struct GenericGemmParams {
     const void* addend;           // bf16 [rows][n_out] added as addend * addend_scale (shared expert) or null
     int64_t addend_stride;
     float addend_scale;
+    // split-K (GG_PLAIN, dense rows only): the reduction is cut into `ksplit` ranges of `split_stages` 64-deep stages, every
+    // (tile, range) workgroup writes an fp32 partial [range][row][n_out] and a second launch sums the ranges in order and
+    // applies bias / addend / the output cast.  ksplit <= 1: off.
+    int ksplit, split_stages, split_rows;
+    float* partial;
 };
+
+// split-K plan of a small-M dense GEMM (same answer for the workspace size and for the launch): 1 = no split
+int generic_ksplit(int M, int N, int K);
 
 int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream);
 // m-tile table of a dense problem (one "expert"); identity_slots (optional, [M]) = 0..M-1 for the tuned kernels' row lookup
