@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
     const int stages_all = (C + kBK - 1) / kBK;
     const int kt0 = split ? ksr * p.split_stages : 0;                               // split_stages is even (fp8 K blocks)
     const int stages = split ? (kt0 + p.split_stages < stages_all ? kt0 + p.split_stages : stages_all) : stages_all;
-    for (int kt = kt0; kt < stages; ++kt) {
-        uint4 xv[2], wv[2];
+    // the operands of stage kt+1 are fetched into registers while stage kt is multiplied out of LDS
+    uint4 xv[2], wv[2];
+    auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = kt * kBK + x_ch[i] * 8;
@@ -188,6 +189,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
                 wv[i] = load8_as_bf16<WTYPE>(w_base[i], k, C);
             }
         }
+    };
+    if (kt0 < stages) fetch(kt0);
+    for (int kt = kt0; kt < stages; ++kt) {
         __syncthreads();   // previous stage's fragment reads are done
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
             *reinterpret_cast<uint4*>(sw + off) = wv[i];
         }
         __syncthreads();
+        if (kt + 1 < stages) fetch(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 xf = *reinterpret_cast<const bf16x8*>(sx + xoff[ks]);
