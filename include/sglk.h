@@ -248,6 +248,25 @@ typedef struct {
 
 int sglk_extend_attention(const sglk_extend_attention_args* args, void* stream);
 
+/* flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, is_causal)
+ *                             (/root/reference/test_flash_attn_varlen.py:100-108; oracle flash_attn_varlen_ref :14-46)
+ * q [Tq][HQ][D], k [Tk][HKV][D], v [Tk][HKV][DV], o [Tq][HQ][DV] bf16, strides in elements; sequence b = rows
+ * cu_seqlens_q[b]..cu_seqlens_q[b+1] of q and cu_seqlens_k[b]..cu_seqlens_k[b+1] of k, v (int32, B+1 entries);
+ * causal = the top-left aligned mask of scaled_dot_product_attention(is_causal=True): query i sees keys 0..i.
+ * D multiple of 8, DV even, both <= 128 (72 / 80 / 94 of the reference's cases run zero-padded). */
+typedef struct {
+    const void* q; int64_t q_stride[2];
+    const void* k; int64_t k_stride[2];
+    const void* v; int64_t v_stride[2];
+    void* o; int64_t o_stride[2];
+    const int32_t* cu_seqlens_q;
+    const int32_t* cu_seqlens_k;
+    int32_t B, max_seqlen_q, HQ, HKV, D, DV;
+    int32_t causal;
+    float sm_scale;
+} sglk_flash_attn_varlen_args;
+int sglk_flash_attn_varlen(const sglk_flash_attn_varlen_args* args, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * decode_attention            replaces torch.ops.sgl_kernel.decode_attention_cpu
  *                             (/root/reference/test_mla.py:115-128, test_decoding.py:107-120)

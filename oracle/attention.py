@@ -49,3 +49,22 @@ def decode_attention(q, k_buffer, v_buffer, key, value, loc, req_to_token, b_req
         k, v = k_buffer[toks].movedim(0, 1), v_buffer[toks].movedim(0, 1)
         out[b] = _attend(q[b].unsqueeze(1), k, v, scale, torch.ones(1, L, dtype=torch.bool), logit_cap).squeeze(1)
     return out
+
+
+def flash_attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, is_causal):
+    """/root/reference/test_flash_attn_varlen.py:14-46: per sequence b, queries = rows cu_q[b]:cu_q[b+1] of q [Tq,H,D],
+    keys/values = rows cu_k[b]:cu_k[b+1] of k [Tk,Hkv,D] / v [Tk,Hkv,DV]; scale 1/sqrt(D); is_causal = the top-left aligned
+    mask of scaled_dot_product_attention (query i sees keys 0..i)."""
+    cu_q, cu_k = cu_seqlens_q.tolist(), cu_seqlens_k.tolist()
+    out = torch.zeros(q.shape[0], q.shape[1], v.shape[2], dtype=torch.float32)
+    scale = 1.0 / q.shape[-1] ** 0.5
+    for b in range(len(cu_k) - 1):
+        qs, qe, ks, ke = cu_q[b], cu_q[b + 1], cu_k[b], cu_k[b + 1]
+        Lq, Lk = qe - qs, ke - ks
+        if is_causal:
+            visible = torch.arange(Lk).view(1, Lk) <= torch.arange(Lq).view(Lq, 1)
+        else:
+            visible = torch.ones(Lq, Lk, dtype=torch.bool)
+        o = _attend(q[qs:qe].transpose(0, 1), k[ks:ke].transpose(0, 1), v[ks:ke].transpose(0, 1), scale, visible)
+        out[qs:qe] = o.transpose(0, 1)
+    return out

@@ -84,19 +84,32 @@ struct TileRegs {
     static constexpr int CH = WIDTH / 8;
     static constexpr int NCH = (kKeys * CH + THREADS - 1) / THREADS;
     uint4 v[NCH];
-    SGLK_DEV void load(const KvSource& src, int p0, int nkeys) {
+    // real_w: valid elements per row (<= WIDTH, even; the image is zero-padded beyond it); aligned: rows and their
+    // 8-element chunks are 16-byte aligned (else the chunk is gathered as four dwords)
+    SGLK_DEV void load(const KvSource& src, int p0, int nkeys, int real_w = WIDTH, bool aligned = true) {
         // two passes: row pointers (page lookups) first, then the row loads back to back
         const unsigned short* rp[NCH];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * THREADS;
             const int row = c / CH, ch = c - row * CH;
-            rp[i] = (c < kKeys * CH && row < nkeys) ? kv_row(src, p0 + row) + ch * 8 : nullptr;
+            rp[i] = (c < kKeys * CH && row < nkeys && ch * 8 < real_w) ? kv_row(src, p0 + row) + ch * 8 : nullptr;
         }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             v[i] = make_uint4(0, 0, 0, 0);
-            if (rp[i]) v[i] = *reinterpret_cast<const uint4*>(rp[i]);
+            if (!rp[i]) continue;
+            const int ch = (threadIdx.x + i * THREADS) % CH;
+            if (aligned && ch * 8 + 8 <= real_w) {
+                v[i] = *reinterpret_cast<const uint4*>(rp[i]);
+            } else {
+                const unsigned* d = reinterpret_cast<const unsigned*>(rp[i]);
+                const int left = real_w - ch * 8;            // 2, 4, 6 or >= 8 valid elements
+                v[i].x = d[0];
+                if (left > 2) v[i].y = d[1];
+                if (left > 4) v[i].z = d[2];
+                if (left > 6) v[i].w = d[3];
+            }
         }
     }
     SGLK_DEV void store(unsigned char* lds) const {
@@ -131,12 +144,13 @@ struct Core {
         }
     }
     // column qt*16 + (lane&15) reads its query row (nullptr = padding column)
-    SGLK_DEV void load_q(int qt, const unsigned short* qrow, int lane) {
+    // d_real: valid elements of the row (multiple of 8, <= D; zero beyond)
+    SGLK_DEV void load_q(int qt, const unsigned short* qrow, int lane, int d_real = D) {
         const int g = lane >> 4;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (qrow) v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + g * 8);
+            if (qrow && ks * 32 + g * 8 < d_real) v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + g * 8);
             qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
         }
     }
@@ -295,10 +309,35 @@ struct ExtendParams {
     const int* b_start_loc_extend;
     int HQ, HKV, HBUF;
     float sm_scale, logit_cap;
+    // flash_attn_varlen_func form (/root/reference/test_flash_attn_varlen.py:100-108): no paged prefix, queries and keys of
+    // sequence b are rows cu_q[b]..cu_q[b+1] of q / cu_k[b]..cu_k[b+1] of k_ext, v_ext; causal = top-left aligned mask
+    int varlen, causal;
+    const int* cu_q;
+    const int* cu_k;
+    int d_real, dv_real;     // head dims of the tensors; the kernel's D / DV are these rounded up (zero-padded images)
+    int v_aligned;           // V rows / chunks are 16-byte aligned
+    int B, nqblk, n_cu, order;   // launch geometry (see the kernel's workgroup-id decomposition)
 };
 
-template <int D, int DV, int QT>
+static int attn_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+static int attn_order(int dflt) {
+    static const char* e = getenv("SGLK_ATTN_ORDER");   // A/B override: bit 0 = flip second wave, bit 1 = heads fastest
+    return e ? atoi(e) : dflt;
+}
+
+// FORM (compile time, so that the extend form pays nothing for the others): 0 = extend_attention_cpu (paged prefix +
+// causal extend part, exact head dims); 1 = flash_attn_varlen_func with head dims equal to D / DV and 16-byte aligned
+// rows; 2 = flash_attn_varlen_func with zero-padded head dims and / or rows that are only 4-byte aligned.
+template <int D, int DV, int QT, int FORM>
 __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendParams p) {
+    constexpr bool VARLEN = FORM != 0, RAGGED = FORM == 2;
     // queries per workgroup: 8 waves (two per SIMD: one wave's softmax beside the other's MFMAs) x QT tiles x 16
     // (QT = 2 where the register budget of 256 per lane allows it)
     constexpr int QB = 8 * QT * 16;
@@ -306,19 +345,46 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
     constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KB + VB)];   // two {K, V} tile buffers
 
-    const int b = blockIdx.y, h = blockIdx.z;
-    const int ext_len = p.b_seq_len_extend[b];
+    // 1-D grid of nqblk * B * HQ workgroups; the linear id is decomposed here so that the order the hardware dispatches
+    // them in can be chosen (p.order bit 1: heads fastest, query blocks slowest = the heaviest query blocks of EVERY
+    // (sequence, head) first; else query blocks fastest.  bit 0: the second CU-count's worth of workgroups is taken in
+    // reverse, so that the two workgroups resident on a CU at the start are a heavy and a light one).
+    // Measured (profiles/r01_v7_attn_order.txt): heads fastest takes causal extend at B=1, ctx=4096, 32 heads from 0.378
+    // to 0.229 ms (all 512 workgroups are resident at once, and with query blocks fastest the CUs that drew two heavy
+    // blocks set the time); the reversal helps only the query-blocks-fastest order and is off by default.
+    int lin = blockIdx.x;
+    {
+        const int total = gridDim.x, hi = 2 * p.n_cu < total ? 2 * p.n_cu : total;
+        if ((p.order & 1) && lin >= p.n_cu && lin < hi) lin = p.n_cu + hi - 1 - lin;
+    }
+    const int nqblk = p.nqblk;
+    int b, h, qblk;
+    if (p.order & 2) { h = lin % p.HQ; b = (lin / p.HQ) % p.B; qblk = lin / (p.HQ * p.B); }
+    else { qblk = lin % nqblk; b = (lin / nqblk) % p.B; h = lin / (nqblk * p.B); }
+    int ext_len, prefix, ext_start, k_start = 0, n_keys;
+    if (VARLEN) {
+        ext_start = p.cu_q[b];
+        ext_len = p.cu_q[b + 1] - ext_start;
+        k_start = p.cu_k[b];
+        n_keys = p.cu_k[b + 1] - k_start;
+        prefix = 0;
+    } else {
+        ext_len = p.b_seq_len_extend[b];
+        prefix = (int)p.b_seq_len[b] - ext_len;
+        ext_start = p.b_start_loc_extend[b];
+        k_start = ext_start;
+        n_keys = prefix + ext_len;
+    }
+    const bool causal = !VARLEN || p.causal;
     // heaviest query blocks (most keys under the causal mask) first
-    const int q0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * QB;
+    const int q0 = (nqblk - 1 - qblk) * QB;
     if (q0 >= ext_len) return;
-    const int seq_len = (int)p.b_seq_len[b];
-    const int prefix = seq_len - ext_len;
-    const int ext_start = p.b_start_loc_extend[b];
-    const int64_t req = p.b_req_idx[b];
+    const int64_t req = VARLEN ? 0 : p.b_req_idx[b];
     const int kvh = h / (p.HQ / p.HKV);
     const int kvh_buf = p.HBUF == p.HKV ? kvh : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d_real = RAGGED ? p.d_real : D, dv_real = RAGGED ? p.dv_real : DV;
     Core<D, DV, QT> core;
     core.init();
     int limit[QT];
@@ -326,19 +392,22 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
     for (int qt = 0; qt < QT; ++qt) {
         const int qi = q0 + wave * WQ + qt * 16 + (lane & 15);
         const bool valid = qi < ext_len;
-        core.load_q(qt, valid ? p.q + (int64_t)(ext_start + qi) * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
-        limit[qt] = valid ? prefix + qi + 1 : 0;     // causal: keys up to and including the query's own position
+        core.load_q(qt, valid ? p.q + (int64_t)(ext_start + qi) * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane, d_real);
+        // causal: keys up to and including the query's own position (never past the sequence's keys)
+        const int vis = causal ? (prefix + qi + 1 < n_keys ? prefix + qi + 1 : n_keys) : n_keys;
+        limit[qt] = valid ? vis : 0;
     }
     KvSource ks, vs;
     const unsigned char* page = reinterpret_cast<const unsigned char*>(p.req_to_tokens) + req * p.rtt_stride * (p.rtt_is64 ? 8 : 4);
     ks.buf = p.k_buf + (int64_t)kvh_buf * p.kb_s1; ks.buf_stride_tok = p.kb_s0; ks.page = page; ks.page_is64 = p.rtt_is64; ks.n_paged = prefix;
-    ks.ext = p.k_ext + (int64_t)ext_start * p.ke_s0 + (int64_t)kvh * p.ke_s1; ks.ext_stride_tok = p.ke_s0;
+    ks.ext = p.k_ext + (int64_t)k_start * p.ke_s0 + (int64_t)kvh * p.ke_s1; ks.ext_stride_tok = p.ke_s0;
     vs = ks;
     vs.buf = p.v_buf + (int64_t)kvh_buf * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
-    vs.ext = p.v_ext + (int64_t)ext_start * p.ve_s0 + (int64_t)kvh * p.ve_s1; vs.ext_stride_tok = p.ve_s0;
+    vs.ext = p.v_ext + (int64_t)k_start * p.ve_s0 + (int64_t)kvh * p.ve_s1; vs.ext_stride_tok = p.ve_s0;
 
     const int q_last = (q0 + QB < ext_len ? q0 + QB : ext_len);
-    const int kv_end = prefix + q_last;       // the block's last query sees keys < prefix + q_last
+    // the block's last query sees keys < prefix + q_last (all keys without the causal mask)
+    const int kv_end = causal ? (prefix + q_last < n_keys ? prefix + q_last : n_keys) : n_keys;
     const float scale_log2e = p.sm_scale * 1.4426950408889634f;
     const int ntiles = (kv_end + kKeys - 1) / kKeys;
 
@@ -347,10 +416,11 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
     TileRegs<DV, 512> vreg;
     // a wave's 32 queries see keys < wave_kv_end: later tiles of the workgroup's stream are fully masked for it
     const int wave_q_last = (q0 + wave * WQ + WQ < ext_len) ? q0 + wave * WQ + WQ : ext_len;
-    const int wave_kv_end = prefix + wave_q_last;
+    const int wave_kv_end = causal ? (prefix + wave_q_last < n_keys ? prefix + wave_q_last : n_keys) : n_keys;
     auto nkeys = [&](int t) { const int r = kv_end - t * kKeys; return r < kKeys ? r : kKeys; };
-    kreg.load(ks, 0, nkeys(0));
-    vreg.load(vs, 0, nkeys(0));
+    const bool v_al = !RAGGED || p.v_aligned != 0;
+    kreg.load(ks, 0, nkeys(0), d_real, true);
+    vreg.load(vs, 0, nkeys(0), dv_real, v_al);
     kreg.store(lds);
     vreg.store(lds + KB);
     __syncthreads();
@@ -359,8 +429,8 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
         unsigned char* nxt = lds + ((t + 1) & 1) * (KB + VB);
         const bool more = t + 1 < ntiles;
         if (more) {
-            kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1));
-            vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1));
+            kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1), d_real, true);
+            vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1), dv_real, v_al);
         }
         if (t * kKeys < wave_kv_end) core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
         if (more) {
@@ -384,7 +454,13 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
             uint2 w;
             w.x = pack_bf16x2(v[0], v[1]);
             w.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(orow + t * 16 + g4) = w;
+            const int c = t * 16 + g4;                       // output dims c .. c+3
+            if (c + 4 <= dv_real && v_al) {
+                *reinterpret_cast<uint2*>(orow + c) = w;
+            } else {                                          // padded tail / rows that are only 4-byte aligned
+                if (c + 2 <= dv_real) *reinterpret_cast<unsigned*>(orow + c) = w.x;
+                if (c + 4 <= dv_real) *reinterpret_cast<unsigned*>(orow + c + 2) = w.y;
+            }
         }
     }
 }
@@ -586,17 +662,22 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
     p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.b_seq_len_extend = a->b_seq_len_extend;
     p.b_start_loc_extend = a->b_start_loc_extend; p.HQ = a->HQ; p.HKV = a->HKV; p.HBUF = a->HBUF;
     p.sm_scale = a->sm_scale; p.logit_cap = a->logit_cap;
+    p.d_real = a->D; p.dv_real = a->DV; p.v_aligned = 1;
     // 16-byte row accesses
     const int64_t strides[] = {p.q_s0, p.q_s1, p.ke_s0, p.ke_s1, p.ve_s0, p.ve_s1, p.kb_s0, p.kb_s1, p.vb_s0, p.vb_s1};
     for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "extend_attention: q/k/v strides must be multiples of 8 elements");
     SGLK_REQUIRE(p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0, SGLK_ERR_SHAPE, "extend_attention: o strides must be multiples of 4 elements");
     const dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
+    p.B = a->B; p.n_cu = attn_cus(); p.order = attn_order(2);
 #define EXT_CASE(DD, DDV)                                                                              \
     if (a->D == DD && a->DV == DDV) {                                                                  \
         constexpr int QT = DD > 128 ? 1 : 2;                                                           \
-        const dim3 grid((unsigned)ceil_div(a->max_len_extend, 8 * QT * 16), (unsigned)a->B, (unsigned)a->HQ); \
-        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT>), grid, block, 0, s, p);              \
+        p.nqblk = (int)ceil_div(a->max_len_extend, 8 * QT * 16);                                       \
+        const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;                                           \
+        SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "extend_attention: too many workgroups");      \
+        const dim3 grid((unsigned)wgs);                                                                \
+        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0>), grid, block, 0, s, p);              \
         SGLK_CHECK_LAUNCH("extend_attention");                                                         \
         return SGLK_OK;                                                                                \
     }
@@ -606,6 +687,61 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
     EXT_CASE(64, 64)
 #undef EXT_CASE
     SGLK_FAIL(SGLK_ERR_SHAPE, "extend_attention: head dims D=%d DV=%d not built (have 128/128, 128/96, 192/128, 64/64)", a->D, a->DV);
+}
+
+// flash_attn_varlen_func (/root/reference/test_flash_attn_varlen.py:100-108; oracle flash_attn_varlen_ref :14-46): plain
+// variable-length attention without a paged prefix, on the extend kernel.  Head dims that are not multiples of 32 / 16
+// (the reference tests 72, 80, 94) run on zero-padded LDS images: q.k is unchanged by zero columns, and the extra value
+// columns are never stored.
+extern "C" int sglk_flash_attn_varlen(const sglk_flash_attn_varlen_args* a, void* stream) {
+    SGLK_REQUIRE(a, SGLK_ERR_INVALID, "flash_attn_varlen: null args");
+    SGLK_REQUIRE(a->B >= 0 && a->HQ > 0 && a->HKV > 0 && a->HQ % a->HKV == 0, SGLK_ERR_INVALID,
+                 "flash_attn_varlen: bad head counts HQ=%d HKV=%d", a->HQ, a->HKV);
+    if (a->B == 0 || a->max_seqlen_q <= 0) return SGLK_OK;
+    SGLK_REQUIRE(a->q && a->k && a->v && a->o && a->cu_seqlens_q && a->cu_seqlens_k, SGLK_ERR_INVALID, "flash_attn_varlen: null pointer");
+    SGLK_REQUIRE(a->D > 0 && a->D % 8 == 0 && a->D <= 128 && a->DV > 0 && a->DV % 2 == 0 && a->DV <= 128, SGLK_ERR_SHAPE,
+                 "flash_attn_varlen: head dims D=%d (multiple of 8, <= 128) DV=%d (even, <= 128) not supported", a->D, a->DV);
+    ExtendParams p{};
+    p.q = (const unsigned short*)a->q; p.k_ext = (const unsigned short*)a->k; p.v_ext = (const unsigned short*)a->v;
+    p.k_buf = p.k_ext; p.v_buf = p.v_ext; p.o = (unsigned short*)a->o;
+    p.q_s0 = a->q_stride[0]; p.q_s1 = a->q_stride[1]; p.ke_s0 = a->k_stride[0]; p.ke_s1 = a->k_stride[1];
+    p.ve_s0 = a->v_stride[0]; p.ve_s1 = a->v_stride[1]; p.kb_s0 = p.ke_s0; p.kb_s1 = p.ke_s1; p.vb_s0 = p.ve_s0; p.vb_s1 = p.ve_s1;
+    p.o_s0 = a->o_stride[0]; p.o_s1 = a->o_stride[1];
+    p.HQ = a->HQ; p.HKV = a->HKV; p.HBUF = a->HKV;
+    p.sm_scale = a->sm_scale; p.logit_cap = 0.f;
+    p.varlen = 1; p.causal = a->causal; p.cu_q = a->cu_seqlens_q; p.cu_k = a->cu_seqlens_k;
+    p.d_real = a->D; p.dv_real = a->DV;
+    SGLK_REQUIRE(p.q_s0 % 8 == 0 && p.q_s1 % 8 == 0 && p.ke_s0 % 8 == 0 && p.ke_s1 % 8 == 0 && ((uintptr_t)a->q % 16) == 0 &&
+                     ((uintptr_t)a->k % 16) == 0, SGLK_ERR_SHAPE, "flash_attn_varlen: q/k rows must be 16-byte aligned");
+    SGLK_REQUIRE(p.ve_s0 % 2 == 0 && p.ve_s1 % 2 == 0 && p.o_s0 % 2 == 0 && p.o_s1 % 2 == 0 && ((uintptr_t)a->v % 4) == 0 &&
+                     ((uintptr_t)a->o % 4) == 0, SGLK_ERR_SHAPE, "flash_attn_varlen: v/o rows must be 4-byte aligned");
+    p.v_aligned = (a->DV % 8 == 0 && p.ve_s0 % 8 == 0 && p.ve_s1 % 8 == 0 && p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0 &&
+                   ((uintptr_t)a->v % 16) == 0 && ((uintptr_t)a->o % 8) == 0) ? 1 : 0;
+    const int Dp = (a->D + 31) / 32 * 32, DVp = (a->DV + 15) / 16 * 16;
+    const bool exact = a->D == Dp && a->DV == DVp && p.v_aligned;
+    p.B = a->B; p.n_cu = attn_cus(); p.order = attn_order(2);
+    p.nqblk = (int)ceil_div(a->max_seqlen_q, 8 * 2 * 16);
+    const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;
+    SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "flash_attn_varlen: too many workgroups");
+    const dim3 block(512);
+    hipStream_t s = (hipStream_t)stream;
+#define FA_CASE(DD, DDV)                                                                               \
+    if (Dp == DD && DVp == DDV) {                                                                      \
+        const dim3 grid((unsigned)wgs);                                                                \
+        if (exact) hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, 2, 1>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, 2, 2>), grid, block, 0, s, p);       \
+        SGLK_CHECK_LAUNCH("flash_attn_varlen");                                                        \
+        return SGLK_OK;                                                                                \
+    }
+    FA_CASE(64, 64)
+    FA_CASE(64, 80)
+    FA_CASE(64, 96)
+    FA_CASE(96, 80)
+    FA_CASE(96, 96)
+    FA_CASE(128, 96)
+    FA_CASE(128, 128)
+#undef FA_CASE
+    SGLK_FAIL(SGLK_ERR_SHAPE, "flash_attn_varlen: padded head dims D=%d DV=%d not built", Dp, DVp);
 }
 
 extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* stream) {

@@ -68,6 +68,19 @@ class ExtendAttentionArgs(ctypes.Structure):
     ]
 
 
+class FlashAttnVarlenArgs(ctypes.Structure):
+    """Mirror of `sglk_flash_attn_varlen_args`."""
+    _fields_ = [
+        ("q", ctypes.c_void_p), ("q_stride", ctypes.c_int64 * 2),
+        ("k", ctypes.c_void_p), ("k_stride", ctypes.c_int64 * 2),
+        ("v", ctypes.c_void_p), ("v_stride", ctypes.c_int64 * 2),
+        ("o", ctypes.c_void_p), ("o_stride", ctypes.c_int64 * 2),
+        ("cu_seqlens_q", ctypes.c_void_p), ("cu_seqlens_k", ctypes.c_void_p),
+        ("B", ctypes.c_int32), ("max_seqlen_q", ctypes.c_int32), ("HQ", ctypes.c_int32), ("HKV", ctypes.c_int32),
+        ("D", ctypes.c_int32), ("DV", ctypes.c_int32), ("causal", ctypes.c_int32), ("sm_scale", ctypes.c_float),
+    ]
+
+
 class DecodeAttentionArgs(ctypes.Structure):
     """Mirror of `sglk_decode_attention_args`."""
     _fields_ = [
@@ -130,6 +143,7 @@ _SIGNATURES = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_void_p]),
     "sglk_extend_attention": (ctypes.c_int, [ctypes.POINTER(ExtendAttentionArgs), ctypes.c_void_p]),
+    "sglk_flash_attn_varlen": (ctypes.c_int, [ctypes.POINTER(FlashAttnVarlenArgs), ctypes.c_void_p]),
     "sglk_decode_attention": (ctypes.c_int, [ctypes.POINTER(DecodeAttentionArgs), ctypes.c_void_p]),
     "sglk_stage_timer_create": (ctypes.c_void_p, [ctypes.c_int32]),
     "sglk_stage_timer_destroy": (None, [ctypes.c_void_p]),

@@ -696,6 +696,34 @@ def extend_attention_cpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     _lib.check(_lib.lib().sglk_extend_attention(ctypes.byref(args), _stream(q_extend)), "extend_attention_cpu")
 
 
+# flash_attn_varlen_func: /root/reference/test_flash_attn_varlen.py:100-108,148-153
+_DEF.define("flash_attn_varlen_func(Tensor q, Tensor k, Tensor v, Tensor cu_seqlens_q, Tensor cu_seqlens_k, "
+            "int max_seqlen_q, int max_seqlen_k, bool causal) -> Tensor")
+
+
+def flash_attn_varlen_func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal):
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _thd(t, "flash_attn_varlen_func: " + n)
+    Tq, HQ, D = q.shape
+    Tk, HKV, DV = v.shape
+    if k.shape[0] != Tk or k.shape[1] != HKV or k.shape[2] != D:
+        raise RuntimeError("flash_attn_varlen_func: k must be [total_k, num_heads_kv, head_dim] like q / v")
+    if cu_seqlens_q.dim() != 1 or cu_seqlens_q.shape != cu_seqlens_k.shape or cu_seqlens_q.numel() < 1:
+        raise RuntimeError("flash_attn_varlen_func: cu_seqlens_q / cu_seqlens_k must be 1-D with batch + 1 entries")
+    cq = cu_seqlens_q.to(torch.int32).contiguous()
+    ck = cu_seqlens_k.to(torch.int32).contiguous()
+    out = torch.empty(Tq, HQ, DV, dtype=q.dtype, device=q.device)
+    args = _lib.FlashAttnVarlenArgs(
+        q=q.data_ptr(), q_stride=_s2(q), k=k.data_ptr(), k_stride=_s2(k), v=v.data_ptr(), v_stride=_s2(v), o=out.data_ptr(),
+        o_stride=_s2(out), cu_seqlens_q=cq.data_ptr(), cu_seqlens_k=ck.data_ptr(), B=cq.numel() - 1,
+        max_seqlen_q=int(max_seqlen_q), HQ=HQ, HKV=HKV, D=D, DV=DV, causal=int(bool(causal)), sm_scale=1.0 / D ** 0.5)
+    _lib.check(_lib.lib().sglk_flash_attn_varlen(ctypes.byref(args), _stream(q)), "flash_attn_varlen_func")
+    return out
+
+
+_impl("flash_attn_varlen_func", flash_attn_varlen_func)
+
+
 def decode_attention_cpu(query, k_buffer, v_buffer, output, key, value, loc, attn_logits, req_to_token, b_req_idx,
                          b_seq_len, sm_scale, logit_cap):
     for t, n in ((query, "query"), (k_buffer, "k_buffer"), (v_buffer, "v_buffer"), (output, "output"), (key, "key"),

@@ -25,6 +25,7 @@ Families -> reference oracle used
   attn      _run_sdpa_forward_extend/decode    /root/reference/test_extend.py:10-76,
                                                /root/reference/test_mla.py:12-66
   absorb    native_torch / native_torch_int8   /root/reference/test_absorb.py:20-109
+  varlen    flash_attn_varlen_ref              /root/reference/test_flash_attn_varlen.py:14-46
 """
 import ast
 import hashlib
@@ -296,8 +297,20 @@ def gen_absorb():
              dict(B=B, hidden=hidden, seed=seed, input_sha256=checksum(inp["hidden_states"], inp["q_a_proj_weight"], inp["w_kc"])))
 
 
+def gen_varlen():
+    """flash_attn_varlen_func: flash_attn_varlen_ref of /root/reference/test_flash_attn_varlen.py:14-46."""
+    ns = lift("test_flash_attn_varlen.py", ["flash_attn_varlen_ref"])
+    for name, batch, mq, mk, H, Hkv, D, DV, causal, varlen, seed in recipes.VARLEN_CASES:
+        inp = recipes.varlen_inputs(batch, mq, mk, H, Hkv, D, DV, varlen, seed)
+        ref = ns["flash_attn_varlen_ref"](inp["q"], inp["k"], inp["v"], inp["cu_q"], inp["cu_k"], is_causal=causal,
+                                          enable_gqa=H != Hkv)
+        save("varlen_" + name, {"ref_out": ref.contiguous()},
+             dict(batch=batch, H=H, Hkv=Hkv, D=D, DV=DV, causal=int(causal), seed=seed,
+                  input_sha256=checksum(inp["q"], inp["k"], inp["v"], inp["cu_q"], inp["cu_k"])))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb}
+            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen}
 
 
 if __name__ == "__main__":

@@ -348,3 +348,34 @@ def absorb_inputs(B, hidden, seed):
         cos_sin_cache=torch.randn(100, d["qk_rope_head_dim"], generator=g).to(bf),
     )
     return out
+
+
+# name, batch, max_q, max_k, H, Hkv, D, DV, causal, varlen, seed     (/root/reference/test_flash_attn_varlen.py:111-116, bench :160)
+VARLEN_CASES = [
+    ("b1_q123_k45_h1_d128_dv96", 1, 123, 45, 1, 1, 128, 96, False, False, 9211),
+    ("b4_h32x4_d64_dv94", 4, 160, 60, 32, 4, 64, 94, False, True, 9212),
+    ("b4_h32x4_d64_dv72_causal", 4, 160, 60, 32, 4, 64, 72, True, True, 9213),
+    ("b4_h32x4_d64_dv80_causal", 4, 160, 60, 32, 4, 64, 80, True, True, 9214),
+    ("b4_h32x4_d64_dv96_causal_fixed", 4, 160, 60, 32, 4, 64, 96, True, False, 9215),
+    ("b4_h32x4_d64_dv96_fixed", 4, 160, 60, 32, 4, 64, 96, False, False, 9216),
+    ("b3_q700_k700_h6_d72_causal", 3, 700, 700, 6, 6, 72, 72, True, True, 9217),
+]
+
+
+def varlen_inputs(batch, max_q, max_k, H, Hkv, D, DV, varlen, seed):
+    """/root/reference/test_flash_attn_varlen.py:63-86."""
+    g = _gen(seed)
+    if varlen:
+        sq = torch.randint(1, max_q, (batch,), generator=g, dtype=torch.int32)
+        sk = torch.randint(1, max_k, (batch,), generator=g, dtype=torch.int32)
+    else:
+        sq = torch.full((batch,), max_q, dtype=torch.int32)
+        sk = torch.full((batch,), max_k, dtype=torch.int32)
+    cu_q = torch.zeros(batch + 1, dtype=torch.int32)
+    cu_k = torch.zeros(batch + 1, dtype=torch.int32)
+    cu_q[1:] = torch.cumsum(sq, 0)
+    cu_k[1:] = torch.cumsum(sk, 0)
+    bf = torch.bfloat16
+    return dict(q=torch.randn(int(sq.sum()), H, D, generator=g).to(bf), k=torch.randn(int(sk.sum()), Hkv, D, generator=g).to(bf),
+                v=torch.randn(int(sk.sum()), Hkv, DV, generator=g).to(bf), cu_q=cu_q, cu_k=cu_k, max_q=int(sq.max()),
+                max_k=int(sk.max()))

@@ -259,6 +259,15 @@ def test_oracle_decode_attention(case):
     assert torch.equal(kb[inp["loc"]], inp["key"])
 
 
+@pytest.mark.parametrize("case", recipes.VARLEN_CASES, ids=lambda c: c[0])
+def test_oracle_flash_attn_varlen(case):
+    name, batch, max_q, max_k, H, Hkv, D, DV, causal, varlen, seed = case
+    g, _ = load_golden("varlen_" + name)
+    inp = recipes.varlen_inputs(batch, max_q, max_k, H, Hkv, D, DV, varlen, seed)
+    out = oattn.flash_attn_varlen(inp["q"], inp["k"], inp["v"], inp["cu_q"], inp["cu_k"], causal)
+    assert moe.allclose_ref(g["ref_out"], out.bfloat16())
+
+
 # ---- qkv_proj_with_rope (oracle/absorb.py vs the reference's native_torch / native_torch_int8) --------------------------
 @pytest.mark.parametrize("case", recipes.ABSORB_CASES, ids=lambda c: c[0])
 def test_absorb_oracle_matches_reference_oracle(case):

@@ -200,6 +200,18 @@ def bench_attn():
         flop = B * HQ * (CTX * CTX / 2) * 2 * (D + DV)     # causal
         emit(op="extend_attention", B=B, ctx=CTX, HQ=HQ, HKV=HKV, D=D, DV=DV, ms=round(ms, 4),
              tflops=round(flop / ms / 1e9, 2), roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
+    # flash_attn_varlen_func: the reference's own bench point (/root/reference/test_flash_attn_varlen.py:117-162:
+    # B = 6 sequences of T = 8160, H = Hkv = 6, head dim 72, non-causal) plus causal / GQA / d128 variants
+    for (B, T, H, HKV, D, causal) in ((6, 8160, 6, 6, 72, False), (6, 8160, 6, 6, 72, True), (4, 4096, 32, 4, 128, True),
+                                      (4, 4096, 32, 4, 64, False)):
+        q = torch.randn(B * T, H, D, device="cuda", generator=g).to(dt)
+        k = torch.randn(B * T, HKV, D, device="cuda", generator=g).to(dt)
+        v = torch.randn(B * T, HKV, D, device="cuda", generator=g).to(dt)
+        cu = (torch.arange(B + 1, device="cuda", dtype=torch.int32) * T)
+        ms = timed(lambda i: ops.flash_attn_varlen_func(q, k, v, cu, cu, T, T, causal), 10)
+        flop = B * H * T * T * 4 * D * (0.5 if causal else 1.0)
+        emit(op="flash_attn_varlen_func", B=B, T=T, H=H, HKV=HKV, D=D, causal=causal, ms=round(ms, 4),
+             tflops=round(flop / ms / 1e9, 2), roofline_frac=round(flop / ms / 1e9 / PEAK_BF16, 4), bound="mfma")
     for (B, HQ, HKV, D, DV, S, alias) in ((1, 22, 1, 576, 512, 1024, True), (40, 22, 1, 576, 512, 1064, True),
                                             (128, 22, 1, 576, 512, 4096, True), (64, 32, 4, 128, 128, 4096, False)):
         total = B * S
