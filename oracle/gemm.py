@@ -34,3 +34,9 @@ def int8_scaled_mm(xq, x_scale, wq, w_scale, bias=None):
     if bias is not None:
         out = out + bias.float().view(1, -1)
     return out
+
+
+def bmm(mat1, mat2):
+    """bmm_cpu (/root/reference/test_bmm_fp8.py:57,67): out[b] = mat1[b] @ mat2[b]^T with mat2 [B, N, K]; fp32 here, the
+    caller rounds to bf16."""
+    return torch.bmm(mat1.float(), mat2.float().transpose(1, 2))

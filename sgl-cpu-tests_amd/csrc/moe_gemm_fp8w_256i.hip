@@ -221,6 +221,10 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             xrow = (int64_t)(pos0 + rr) * p.x_stride;
         }
         xsrc[i] = (unsigned)(xrow * 2) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) << 4);   // image swizzle: chunk ^ ((row>>1)&7)
+        // rows past the tile's last one: an offset outside the descriptor's range.  The load still counts in vmcnt
+        // (the stage waits are literals) but fetches nothing, so a tail tile with 40 rows does not pull 256 rows
+        // through L2; whatever the LDS rows then hold only reaches accumulator columns that are never stored.
+        if (r >= rows) xsrc[i] = xbytes;
     }
     unsigned wsrc[2];
 #pragma unroll

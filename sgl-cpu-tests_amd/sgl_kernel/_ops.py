@@ -696,6 +696,32 @@ def extend_attention_cpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
     _lib.check(_lib.lib().sglk_extend_attention(ctypes.byref(args), _stream(q_extend)), "extend_attention_cpu")
 
 
+# bmm_cpu: /root/reference/test_bmm_fp8.py:38-39,67,73 -- out[b] = mat1[b] @ mat2[b]^T, bf16, strided out / mat1 views
+_DEF.define("bmm_cpu(Tensor(a!) out, Tensor mat1, Tensor mat2, bool is_vnni, Tensor? scale) -> ()")
+
+
+def bmm_cpu(out, mat1, mat2, is_vnni, scale):
+    if scale is not None:
+        raise RuntimeError("bmm_cpu: scaled (fp8) mat2 is not supported; the reference harness passes scale=None")
+    for t, n in ((out, "out"), (mat1, "mat1"), (mat2, "mat2")):
+        if t.dim() != 3 or t.dtype != torch.bfloat16:
+            raise RuntimeError(f"bmm_cpu: {n} must be a 3-D bfloat16 tensor")
+    Bn, M, K = mat1.shape
+    N = mat2.shape[1]
+    if mat2.shape[0] != Bn or mat2.shape[2] != K or tuple(out.shape) != (Bn, M, N):
+        raise RuntimeError(f"bmm_cpu: shapes out {tuple(out.shape)}, mat1 {tuple(mat1.shape)}, mat2 [B, N, K] "
+                           f"{tuple(mat2.shape)} do not agree")
+    if mat1.stride(2) != 1 or out.stride(2) != 1 or not mat2.is_contiguous():
+        raise RuntimeError("bmm_cpu: out / mat1 need a contiguous last dim, mat2 must be contiguous [B, N, K]")
+    # kernel naming: "heads" = the bmm batch, "rows" = M (sglk.h: out[b][h][oc] = sum_ic x[b][h][ic] * w[h][oc][ic])
+    packed = 1 if (is_vnni and _pack_supported(N, K, mat2.dtype)) else 0
+    _lib.check(_lib.lib().sglk_bmm_heads(_ptr(mat1), mat1.stride(1), mat1.stride(0), _ptr(mat2), packed, _ptr(out),
+                                         out.stride(1), out.stride(0), M, Bn, N, K, _stream(out)), "bmm_cpu")
+
+
+_impl("bmm_cpu", bmm_cpu, lambda a, args: a is args[0])
+
+
 # flash_attn_varlen_func: /root/reference/test_flash_attn_varlen.py:100-108,148-153
 _DEF.define("flash_attn_varlen_func(Tensor q, Tensor k, Tensor v, Tensor cu_seqlens_q, Tensor cu_seqlens_k, "
             "int max_seqlen_q, int max_seqlen_k, bool causal) -> Tensor")

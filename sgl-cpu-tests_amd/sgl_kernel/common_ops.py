@@ -19,3 +19,4 @@ grouped_topk_cpu = torch.ops.sgl_kernel.grouped_topk_cpu
 biased_grouped_topk_cpu = torch.ops.sgl_kernel.biased_grouped_topk_cpu
 qkv_proj_with_rope = torch.ops.sgl_kernel.qkv_proj_with_rope
 flash_attn_varlen_func = torch.ops.sgl_kernel.flash_attn_varlen_func
+bmm_cpu = torch.ops.sgl_kernel.bmm_cpu

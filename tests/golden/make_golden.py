@@ -309,8 +309,18 @@ def gen_varlen():
                   input_sha256=checksum(inp["q"], inp["k"], inp["v"], inp["cu_q"], inp["cu_k"])))
 
 
+def gen_bmm():
+    """bmm_cpu: the reference's expectation is torch.bmm(matA, matB) on bf16 (/root/reference/test_bmm_fp8.py:57, matB =
+    mat2 viewed [B, K, N])."""
+    for name, B, M, N, K, chunk, seed in recipes.BMM_CASES:
+        inp = recipes.bmm_inputs(B, M, N, K, chunk, seed)
+        ref = torch.bmm(inp["mat1"], inp["mat2"].transpose(1, 2))
+        save("bmm_" + name, {"ref_out": ref.contiguous()},
+             dict(B=B, M=M, N=N, K=K, seed=seed, input_sha256=checksum(inp["mat1"].contiguous(), inp["mat2"])))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen}
+            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen, "bmm": gen_bmm}
 
 
 if __name__ == "__main__":

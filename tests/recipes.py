@@ -379,3 +379,21 @@ def varlen_inputs(batch, max_q, max_k, H, Hkv, D, DV, varlen, seed):
     return dict(q=torch.randn(int(sq.sum()), H, D, generator=g).to(bf), k=torch.randn(int(sk.sum()), Hkv, D, generator=g).to(bf),
                 v=torch.randn(int(sk.sum()), Hkv, DV, generator=g).to(bf), cu_q=cu_q, cu_k=cu_k, max_q=int(sq.max()),
                 max_k=int(sk.max()))
+
+
+# name, B, M, N, K, chunk, seed      (/root/reference/test_bmm_fp8.py:122-126: m in {1, 2, 11, 111}, two shapes, + (1, 5, 96, 160))
+BMM_CASES = [(f"b17_m{m}_n160_k544", 17, m, 160, 544, True, 9400 + m) for m in (1, 2, 11, 111)] + \
+            [(f"b16_m{m}_n512_k160", 16, m, 512, 160, True, 9500 + m) for m in (1, 2, 11, 111)] + \
+            [("b1_m5_n96_k160", 1, 5, 96, 160, True, 9600), ("b3_m7_n40_k72_plain", 3, 7, 40, 72, False, 9601)]
+
+
+def bmm_inputs(B, M, N, K, chunk, seed):
+    """/root/reference/test_bmm_fp8.py:43-50: mat1 [B, M, K] as a transposed (and, with `chunk`, narrowed) view of
+    [M, B, K(+64)]; mat2 [B, N, K] contiguous; out [B, M, N] the same kind of view."""
+    g = _gen(seed)
+    bf = torch.bfloat16
+    pad = 64 if chunk else 0
+    mat1 = torch.randn(M, B, K + pad, generator=g).to(bf).narrow(2, 0, K).transpose(0, 1)
+    mat2 = torch.randn(B, N, K, generator=g).to(bf)
+    out = torch.zeros(M, B, N + pad, dtype=bf).narrow(2, 0, N).transpose(0, 1)
+    return dict(mat1=mat1, mat2=mat2, out=out)

@@ -268,6 +268,15 @@ def test_oracle_flash_attn_varlen(case):
     assert moe.allclose_ref(g["ref_out"], out.bfloat16())
 
 
+@pytest.mark.parametrize("case", recipes.BMM_CASES, ids=lambda c: c[0])
+def test_oracle_bmm(case):
+    from oracle import gemm as ogemm
+    name, B, M, N, K, chunk, seed = case
+    g, _ = load_golden("bmm_" + name)
+    inp = recipes.bmm_inputs(B, M, N, K, chunk, seed)
+    assert moe.allclose_ref(g["ref_out"], ogemm.bmm(inp["mat1"], inp["mat2"]).bfloat16())
+
+
 # ---- qkv_proj_with_rope (oracle/absorb.py vs the reference's native_torch / native_torch_int8) --------------------------
 @pytest.mark.parametrize("case", recipes.ABSORB_CASES, ids=lambda c: c[0])
 def test_absorb_oracle_matches_reference_oracle(case):
