@@ -20,11 +20,14 @@ struct Workspace {
     size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tickets, ic1, ic2, xq, xs, ic1q, ic1s, total;
 };
 
-// Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E):
-//   <  44 rows : 32-token tiles, weight-streaming kernel (HBM-bound regime: every touched expert's weights are read once;
-//                measured crossover against the 256 kernel at Qwen3 dims: M ~ 700)
-//   >= 44 rows : 256-token tiles, 8-wave LDS-DMA ring kernel (faster than 128-row tiles at every M measured, 768..8192)
-//   shapes the two cannot take (K % 256, very large operands): 128-token tiles
+// Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E).  Measured crossovers at Qwen3
+// dims (tools/moe_stage_sweep.py, profiles/r01_v7_stage_sweep.txt):
+//   <   8 rows : 32-token tiles, weight-streaming kernel, activations whole in LDS (decode: M < 128)
+//   <  72 rows : up to 96-token tiles, weight-streaming kernel with K-blocked activations (M = 128 .. 1151): every touched
+//                expert's weights are read ONCE (a 32-token tile reads them 2-3 times, a 256-token tile wastes its ring
+//                and half its waves on padding); GEMM-1 runs at 4.5-5.5 TB/s of weight stream
+//   >= 72 rows : 256-token tiles, 8-wave LDS-DMA ring kernel
+//   shapes these cannot take (K % 256, very large operands): 128-token tiles
 int pick_tile_m(int M, int N, int K, int E, int topk) {
     const char* force = getenv("SGLK_MOE_TILE_M");
     const int64_t S = (int64_t)M * topk;
@@ -34,13 +37,21 @@ int pick_tile_m(int M, int N, int K, int E, int topk) {
     // stream kernel: both reduction lengths (K for GEMM-1, N for GEMM-2) must be multiples of 256 (ring of 8 pieces)
     const bool ok_stream = (K % 256 == 0) && (N % 256 == 0) && (int64_t)kStreamTileM * K * 2 <= 150 * 1024 &&
                            (int64_t)kStreamTileM * N * 2 <= 150 * 1024;
+    // mid kernel: reduction lengths in whole 256s up to 4096 (scale table), 128 ic1 / 256 output columns per workgroup
+    const bool ok_mid = (K % 256 == 0) && (N % 256 == 0) && K <= 4096 && N <= 4096;
     if (force) {
         const int f = atoi(force);
         if (f == 256 && ok256) return 256;
         if (f == 32 && ok_stream) return kStreamTileM;
+        if (f == kMidTileM && ok_mid) return kMidTileM;
         if (f == 128) return 128;
     }
-    if (ok_stream && S < (int64_t)44 * E) return kStreamTileM;
+    static const char* lo_env = getenv("SGLK_MID_LO");   // A/B overrides of the two crossovers (average rows per expert)
+    static const char* hi_env = getenv("SGLK_MID_HI");
+    const int64_t lo = lo_env ? atoi(lo_env) : 8, hi = hi_env ? atoi(hi_env) : 72;
+    if (ok_stream && S < lo * E) return kStreamTileM;
+    if (ok_mid && S < hi * E) return kMidTileM;
+    if (ok_stream && !ok_mid && S < (int64_t)44 * E) return kStreamTileM;
     return ok256 ? 256 : kTileM;
 }
 
@@ -205,6 +216,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_GATE_UP, g1, max_tiles, s)
                                     : launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s))
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_GATE_UP, g1, max_tiles, s)
+             : tile_m == kMidTileM    ? launch_moe_gemm_fp8w_mid(MODE_GATE_UP, g1, max_tiles, s)
                                       : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
@@ -225,7 +237,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.n_half = 0;
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
-        g2.n_tiles = tile_m == 128 ? K / 128 : K / 256;
+        g2.n_tiles = (tile_m == 128 || tile_m == kMidTileM) ? K / 128 : K / 256;
         g2.out = ic2;
         g2.out_stride = K;
         g2.topk_weights = a->topk_weights;
@@ -236,6 +248,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_DOWN, g2, max_tiles, s)
                                     : launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s))
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)
+             : tile_m == kMidTileM    ? launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s)
                                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);

@@ -1,0 +1,279 @@
+// Mid-M grouped W8A16 GEMM of fused_experts: weight-STREAMING kernel for experts that see a few dozen to ~128 rows
+// (M ~ 300 .. 2000 at Qwen3-30B-A3B).  The call is still bound by reading every expert's fp8 weights once (604 MB),
+// but a 32-token tile (moe_gemm_fp8w_stream.hip) would read them two to four times and a 256-token tile
+// (moe_gemm_fp8w_256i.hip) spends its LDS ring and half its waves on padding rows.
+//
+// Same math contract as moe_gemm_fp8w.hip (oracle /root/reference/test_moe_fp8_ext.py:22-25,70-91).
+//
+// * tile = up to 96 tokens x 16 (GATE_UP) or 8 (DOWN) weight row-tiles per workgroup of 8 waves; every wave owns two
+//   16-row weight tiles (GATE_UP: the gate tile and the matching up tile, so SiLU*mul stays in-register) or one (DOWN:
+//   two workgroups per CU) for ALL the tile's tokens;
+// * the number of 16-token MFMA column tiles is the tile's own (MT = ceil(rows / 16), rounded to 2 / 4 / 6 and
+//   compiled as separate loop bodies): math, LDS traffic and accumulator registers follow the rows that exist;
+// * weights never touch LDS: a packed piece (16 rows x 64 k = 1 KiB, pack.hip) is one global_load_dwordx4 per lane and
+//   lands in MFMA A-operand order.  Each wave keeps 8 pieces = two 128-wide K blocks of its two tiles in flight
+//   (statically indexed registers), 64 KiB per CU;
+// * activations go through LDS one 128-wide K block at a time (tokens x 256 B, 16-byte chunks XOR-swizzled by
+//   row & 15), double buffered: block kb+1 travels global -> LDS by DMA (no registers; the swizzle is applied to the
+//   source address) while block kb is multiplied, one counted s_waitcnt + one barrier per block.  Each token fragment read feeds both of the wave's
+//   weight tiles (8 MFMAs per 4 ds_read_b128);
+// * fp8 -> bf16 exactly (v_cvt_scalef32_pk_bf16_fp8, scale 1.0); the 128-block partial sum lives in a temporary and
+//   is folded into the accumulator with the block scale in fp32.
+#include "sglk_common.h"
+#include "moe_internal.h"
+
+namespace sglk {
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+namespace gmid {
+
+constexpr int kTM = kMidTileM;        // 128 tokens
+constexpr int kXBuf = kTM * 256;      // one K block of the token tile: 32 KiB
+constexpr int kScOff = 2 * kXBuf;     // then the scale table [8 waves][2 tiles][32 K blocks] f32
+constexpr int kRowTabOff = kScOff + 8 * 2 * 32 * 4;   // DOWN: output slot and routing weight of every tile row
+constexpr int kLds = kRowTabOff + 2 * kTM * 4;
+
+SGLK_DEV bf16x8 cvt8(unsigned lo, unsigned hi) {
+    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false);
+    const bf16x2 b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false);
+    const bf16x2 d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+    r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+    return r;
+}
+
+struct TileCtx {
+    int pos0, rows, ntile, kblocks;
+    const unsigned char* wp[2];   // lane's byte inside the first piece of the wave's two weight row-tiles
+    const float* sc;              // LDS: this wave's [2][32] block scales
+    int row16[2];
+};
+
+// Everything after the tile lookup, for MT 16-token column tiles.  TPW = weight row-tiles per wave: 2 for GATE_UP (gate +
+// up), 1 for DOWN -- half the registers, so that two workgroups share a CU and one's prologue (tile table -> rows ->
+// first activations, three dependent round trips) and epilogue hide behind the other's stream; DOWN's reduction is
+// short (N = 768: six K blocks), so without that overlap the prologue is a third of its time.
+template <int MODE, int MT>
+SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
+    // DOWN: the rows' output slots and routing weights are two dependent round trips; they start here and wait in LDS
+    // for the epilogue instead of being fetched by it
+    int my_slot = -1;
+    float my_tw = 0.f;
+    if (MODE == MODE_DOWN && (int)threadIdx.x < c.rows) my_slot = p.sorted_slot[c.pos0 + threadIdx.x];
+    constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
+    constexpr int PB = 2 * TPW;          // weight pieces per K block per wave
+    // the weight stream starts before anything else: K blocks 0 and 1 of the wave's tiles; ring slot = block*PB + tile*2
+    // + k half
+    u32x4 ring[2 * PB];
+#pragma unroll
+    for (int i = 0; i < 2 * PB; ++i)
+        ring[i] = *reinterpret_cast<const u32x4*>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int XV = MT / 2;           // 1-KiB LDS-DMA pieces (4 rows x 256 B) of a K block per wave: MT*16 rows / 4 / 8
+
+    // ---- activations: global -> LDS by DMA, no registers.  Piece q = wave*XV + j holds rows 4q .. 4q+3; lane l lands at
+    //      byte 16*l of the piece (row 4q + (l>>4), chunk position l&15), so the swizzle is applied to the SOURCE chunk --
+    const uint16_t* xsrc[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const int row = (wave * XV + j) * 4 + (lane >> 4), ch = (lane & 15) ^ (row & 15);
+        // rows past the tile's last one re-read that last row: whatever they hold only reaches accumulator columns that
+        // are never stored, and an unconditional load keeps control flow out of the pipeline
+        const int rr = row < c.rows ? row : c.rows - 1;
+        int64_t xrow;
+        if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[c.pos0 + rr] / p.topk) * p.x_stride;
+        else xrow = (int64_t)(c.pos0 + rr) * p.x_stride;
+        xsrc[j] = p.x + xrow + ch * 8;
+    }
+    auto x_dma = [&](int kb) __attribute__((always_inline)) {
+        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+#pragma unroll
+        for (int j = 0; j < XV; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + kb * 128), (lptr_t)(dst + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TPW][MT];
+#pragma unroll
+    for (int a = 0; a < TPW; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[a][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto piece_ptr = [&](int kb, int j) __attribute__((always_inline)) { return c.wp[j >> 1] + (int64_t)(2 * kb + (j & 1)) * 1024; };
+
+    // one 128-wide K block: ring slots PB*half .. = (tile0,k0) (tile0,k1) [(tile1,k0) (tile1,k1)]
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
+        // block kb+1's activations first, then the weight refills: loads retire in order, so "all but the newest PB
+        // loads have landed" at the end of the block means the activations (and the weights of block kb+1) are in
+        if (prefetch_x) x_dma(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 w[TPW][4];   // [tile][k-step of the block]
+#pragma unroll
+        for (int a = 0; a < TPW; ++a) {
+            const u32x4 r0 = ring[half * PB + 2 * a], r1 = ring[half * PB + 2 * a + 1];
+            w[a][0] = cvt8(r0[0], r0[1]);
+            w[a][1] = cvt8(r0[2], r0[3]);
+            w[a][2] = cvt8(r1[0], r1[1]);
+            w[a][3] = cvt8(r1[2], r1[3]);
+        }
+        if (refill) {
+#pragma unroll
+            for (int j = 0; j < PB; ++j) ring[half * PB + j] = *reinterpret_cast<const u32x4*>(piece_ptr(kb + 2, j));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float sc[TPW];
+#pragma unroll
+        for (int a = 0; a < TPW; ++a) sc[a] = c.sc[a * 32 + kb];
+        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int xr = mt * 16 + r;
+            const unsigned char* base = xb + xr * 256;
+            bf16x8 x[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x[s] = *reinterpret_cast<const bf16x8*>(base + (((s * 4 + g) ^ (xr & 15)) << 4));
+            f32x4 t[TPW];
+#pragma unroll
+            for (int a = 0; a < TPW; ++a) t[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < TPW; ++a) t[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[a][s], x[s], t[a], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TPW; ++a) acc[a][mt] += sc[a] * t[a];
+        }
+        if (prefetch_x) {   // the DMA target was last read in block kb-1, which every wave left before the barrier that closed it
+            // the waits are builtins, not inline asm: the compiler's own wait-count pass sees them and knows the DMA has
+            // landed; behind an opaque asm it re-waits with vmcnt(0) in front of the next LDS read and drains the ring
+            if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB)
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+
+    if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];
+    x_dma(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): block 0's activations and the scale table
+    int* slot_tab = reinterpret_cast<int*>(lds + kRowTabOff);
+    float* tw_tab = reinterpret_cast<float*>(lds + kRowTabOff + kTM * 4);
+    if (MODE == MODE_DOWN && tid < kTM) {
+        slot_tab[tid] = my_slot;
+        tw_tab[tid] = my_tw;
+    }
+    __syncthreads();
+    // kblocks is even and >= 2 (C % 256 == 0).  The steady state has no branch between a load and its use (with one the
+    // compiler falls back to s_waitcnt vmcnt(0) per piece and the ring degenerates)
+    int kb = 0;
+    for (; kb + 2 < c.kblocks; kb += 2) {
+        block(kb, 0, true, true);
+        block(kb + 1, 1, true, true);
+    }
+    block(kb, 0, false, true);
+    block(kb + 1, 1, false, false);
+
+    // ---- epilogue: lane holds weight rows 4g..4g+3 of each tile for token r of every column tile ----------------------
+    const int q4 = g * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int tr = mt * 16 + r;
+        if (tr >= c.rows) continue;
+        if (MODE == MODE_GATE_UP) {
+            const f32x4 gt = acc[0][mt], up = acc[TPW - 1][mt];
+            uint2 v;
+            v.x = pack_bf16x2(silu_f32(gt[0]) * up[0], silu_f32(gt[1]) * up[1]);
+            v.y = pack_bf16x2(silu_f32(gt[2]) * up[2], silu_f32(gt[3]) * up[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + c.ntile * 128 + wave * 16 + q4) = v;
+        } else {
+            const int slot = slot_tab[tr];
+            const float tw = tw_tab[tr];
+            uint16_t* orow = p.out + (int64_t)slot * p.out_stride + c.ntile * 128 + wave * 16 + q4;
+            const f32x4 v4 = acc[0][mt] * tw;
+            uint2 v;
+            v.x = pack_bf16x2(v4[0], v4[1]);
+            v.y = pack_bf16x2(v4[2], v4[3]);
+            *reinterpret_cast<uint2*>(orow) = v;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 1 : 2) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int live = p.num_tiles[0] * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int L = xcd_remap(blockIdx.x, live);
+    const int mtile = L / p.n_tiles;
+    const int4 ti = p.tile_info[mtile];
+    const int e = __builtin_amdgcn_readfirstlane(ti.x);
+
+    TileCtx c;
+    c.ntile = L - mtile * p.n_tiles;
+    c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+    c.rows = __builtin_amdgcn_readfirstlane(ti.z);
+    c.kblocks = p.C >> 7;
+    const int ctiles = p.C >> 6;
+    if (MODE == MODE_GATE_UP) {          // workgroup = 128 ic1 columns: wave w -> columns ntile*128 + 16w .. +15
+        c.row16[0] = c.ntile * 8 + wave;
+        c.row16[1] = (p.n_half >> 4) + c.ntile * 8 + wave;
+    } else {                             // workgroup = 128 output columns: wave w -> columns ntile*128 + 16w .. +15
+        c.row16[0] = c.ntile * 8 + wave;
+        c.row16[1] = c.row16[0];
+    }
+    const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
+    c.wp[0] = wexp + ((int64_t)c.row16[0] * ctiles) * 1024 + lane * 16;
+    c.wp[1] = wexp + ((int64_t)c.row16[1] * ctiles) * 1024 + lane * 16;
+
+    // block scales of the wave's two tiles -> LDS (read back as broadcasts, one per K block)
+    float* sc = reinterpret_cast<float*>(lds + kScOff) + wave * 64;
+    {
+        const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
+        const int a = lane >> 5, kb = lane & 31;
+        const int srow = ((a ? c.row16[1] : c.row16[0]) * 16) / p.block_n;
+        sc[lane] = kb < c.kblocks ? scale_e[srow * p.scale_cols + kb] : 0.f;
+    }
+    c.sc = sc;
+
+    const int mt = (c.rows + 15) >> 4;
+    if (mt <= 2) run<MODE, 2>(p, lds, c);
+    else if (mt <= 4) run<MODE, 4>(p, lds, c);
+    else run<MODE, 6>(p, lds, c);
+}
+
+}  // namespace gmid
+
+int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks == 0) return SGLK_OK;
+    if (p.C % 256 != 0 || p.C > 4096) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid: reduction length %d (need %% 256 == 0, <= 4096)", p.C);
+    const size_t lds = gmid::kLds;
+    if (mode == MODE_GATE_UP) {
+        static bool attr1 = false;
+        if (!attr1) {
+            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr1 = true;
+        }
+        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    } else {
+        static bool attr2 = false;
+        if (!attr2) {
+            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    }
+    SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

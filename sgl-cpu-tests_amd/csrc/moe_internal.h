@@ -6,6 +6,7 @@ namespace sglk {
 
 constexpr int kTileM = 128;        // tokens (slot rows) per tile of the 128x128 kernel
 constexpr int kStreamTileM = 32;   // tokens per tile of the weight-streaming small-M kernel
+constexpr int kMidTileM = 96;      // tokens per tile (at most) of the weight-streaming mid-M kernel
 
 enum { MODE_GATE_UP = 0, MODE_DOWN = 1, MODE_PLAIN = 2 };   // PLAIN: out[pos] = x.W^T (+bias) (+addend*scale), dense
 
@@ -147,6 +148,10 @@ int launch_quant_int8_rows_f32(const float* x, int64_t x_stride, int8_t* q, int6
 
 // 32-token tiles, weights streamed global -> VGPR (moe_gemm_fp8w_stream.hip); tile table built with tile_m = 32
 int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+
+// up to 128-token tiles, weights streamed global -> VGPR, activations K block by K block through LDS
+// (moe_gemm_fp8w_mid.hip); tile table built with tile_m = 128
+int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
