@@ -107,7 +107,7 @@ def test_fused_experts_fp8_all_masked_and_empty(ops):
     assert tuple(out0.shape) == (0, K)
 
 
-@pytest.mark.parametrize("M", [1, 64, 1000])
+@pytest.mark.parametrize("M", [1, 64, 300, 1000])
 def test_fused_experts_fp8_qwen3_full_experts(ops, M):
     """Qwen3-30B-A3B expert dims with all 128 experts (604 MB of fp8 weights) — BASELINE.json config 2.
 
@@ -147,10 +147,10 @@ def test_cpu_tensors_are_staged_through_the_gpu(ops):
     check_close(out, g["ref_out_f32"], "cpu-staged")
 
 
-@pytest.mark.parametrize("tile_m", ["32", "128", "256"])
+@pytest.mark.parametrize("tile_m", ["32", "96", "128", "256"])
 @pytest.mark.parametrize("block", [(128, 128), (64, 128)])
 def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
-    """Both grouped-GEMM tilings (128-row 2-stage, 256-row 3-deep ring) against the plain-C oracle; ragged expert
+    """Every grouped-GEMM tiling (32- and 96-row weight streaming, 128-row 2-stage, 256-row 3-deep ring) against the plain-C oracle; ragged expert
     loads (rows per expert not a multiple of either tile), wide dynamic range of block scales incl. zero/negative."""
     monkeypatch.setenv("SGLK_MOE_TILE_M", tile_m)
     M, N, K, E, topk = 1531, 256, 512, 8, 4
