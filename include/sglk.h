@@ -41,7 +41,8 @@ enum {
 enum {
     SGLK_W_BF16 = 0,
     SGLK_W_FP8_E4M3 = 1,
-    SGLK_W_INT8 = 2
+    SGLK_W_INT8 = 2,
+    SGLK_W_MXFP4 = 3   /* E2M1 pairs in bytes + E8M0 scales per 32 (sglk_mxfp4_scaled_mm only) */
 };
 
 /* output element types of the dense GEMM entry points */
@@ -170,6 +171,17 @@ typedef struct {
 
 size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
 int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
+
+/* mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py:148,170,201): out[M][N] bf16 = x[M][K] bf16 . dequant(wq, scales)^T
+ * (+ bias f32 [N]).  wq uint8 [N][K/2], element 2i of a row in the low nibble of byte i (E2M1: sign, 2-bit exponent,
+ * 1-bit mantissa -> 0, 0.5, 1, 1.5, 2, 3, 4, 6); scales uint8 E8M0 (2^(s-127)) per 32 consecutive k: [N][K/32] row-major,
+ * or with scale_packed != 0 the order convert_scale_packed returns ([N/32][K/32][32], test_mxfp4.py:186).  The weights
+ * are expanded to bf16 exactly and multiplied on the bf16 matrix cores with fp32 accumulation (W4A16, like the reference;
+ * activations are never quantised).  K % 32 == 0; scale_packed needs N % 32 == 0.  Workspace:
+ * sglk_scaled_mm_workspace_bytes(M, N, K, SGLK_W_BF16, 0). */
+int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void* wq, const void* scales, int32_t scale_packed,
+                         const float* bias, void* out, int64_t out_stride, int32_t M, int32_t N, int32_t K,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* per_token_quant_int8_cpu (/root/reference/test_gemm_int8.py:66): q = rint(x * 127/amax), scale = amax/127,
  * amax = max(|row|, 1e-10).  x bf16 [rows][cols]. */

@@ -40,3 +40,48 @@ def bmm(mat1, mat2):
     """bmm_cpu (/root/reference/test_bmm_fp8.py:57,67): out[b] = mat1[b] @ mat2[b]^T with mat2 [B, N, K]; fp32 here, the
     caller rounds to bf16."""
     return torch.bmm(mat1.float(), mat2.float().transpose(1, 2))
+
+
+E2M1_VALUES = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+E2M1_BOUNDS = (0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0)
+
+
+def mxfp4_quantize(x, block=32):
+    """MXFP4QuantizeUtil.quantize (/root/reference/test_mxfp4.py:23-64): per 32-wide block, scale exponent
+    ceil(log2(amax / 6)) clamped at -127, values to the nearest E2M1 code by the bounds table (ties go down), element 2i
+    in the low nibble of byte i, scale stored as exponent + 127."""
+    shape = x.shape
+    xb = x.reshape(-1, block)
+    amax = xb.abs().max(dim=-1, keepdim=True).values
+    e = torch.ceil(torch.maximum(torch.log2(amax / 6.0), torch.tensor(-127.0)))
+    q = (xb / torch.exp2(e)).reshape(shape)
+    sign_bit = (2 - torch.sign(q)) // 2
+    code = (q.abs().unsqueeze(-1) > torch.tensor(E2M1_BOUNDS)).sum(dim=-1)
+    nib = (sign_bit * 8 + code).to(torch.uint8)
+    packed = (nib[..., 1::2] << 4) + nib[..., 0::2]
+    return packed, (e + 127).to(torch.uint8)
+
+
+def mxfp4_dequant(wq, scales, block=32):
+    """MXFP4QuantizeUtil.dequantize (/root/reference/test_mxfp4.py:66-127) in fp32: nibble -> +-E2M1 value, times
+    2^(scale - 127) per 32 consecutive elements of a row."""
+    lo, hi = wq & 0x0F, (wq >> 4) & 0x0F
+    nib = torch.stack([lo, hi], dim=-1).reshape(*wq.shape[:-1], wq.shape[-1] * 2)
+    sign = 1.0 - 2.0 * ((nib & 8) >> 3).float()
+    val = sign * torch.tensor(E2M1_VALUES)[(nib & 7).long()]
+    sc = torch.exp2(scales.float() - 127.0).reshape(-1, 1)
+    return (val.reshape(-1, block) * sc).reshape(nib.shape)
+
+
+def mxfp4_scaled_mm(x, wq, scales, bias=None):
+    """mxfp4_scaled_mm_cpu's expectation (/root/reference/test_mxfp4.py:166-168): fp32 matmul against the dequantised
+    weights (exactly representable in bf16), + bias; fp32 here, the caller rounds."""
+    out = x.float() @ mxfp4_dequant(wq, scales).t()
+    return out if bias is None else out + bias.float().view(1, -1)
+
+
+def scale_packed_order(scales):
+    """convert_scale_packed's layout as the reference checks it (/root/reference/test_mxfp4.py:186):
+    [N, K/32] -> [N/32][K/32][32]."""
+    n, kb = scales.shape
+    return scales.view(n // 32, 32, kb).transpose(1, 2).contiguous()

@@ -354,3 +354,59 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     }
     return launch_gemm_generic(GG_PLAIN, g, tiles, s);
 }
+
+extern "C" int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void* wq, const void* scales, int32_t scale_packed,
+                                    const float* bias, void* out, int64_t out_stride, int32_t M, int32_t N, int32_t K,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, SGLK_ERR_INVALID, "mxfp4_scaled_mm: bad sizes M=%d N=%d K=%d", M, N, K);
+    SGLK_REQUIRE(K % 32 == 0, SGLK_ERR_SHAPE, "mxfp4_scaled_mm: K (%d) must be a multiple of the 32-wide scale block", K);
+    SGLK_REQUIRE(!scale_packed || N % 32 == 0, SGLK_ERR_SHAPE, "mxfp4_scaled_mm: packed scales need N (%d) %% 32 == 0", N);
+    SGLK_REQUIRE(wq && scales && workspace, SGLK_ERR_INVALID, "mxfp4_scaled_mm: null pointer");
+    SGLK_REQUIRE(M == 0 || (x && out), SGLK_ERR_INVALID, "mxfp4_scaled_mm: null pointer");
+    SGLK_REQUIRE(x_stride >= K && out_stride >= N, SGLK_ERR_INVALID, "mxfp4_scaled_mm: row stride too small");
+    SGLK_REQUIRE(((uintptr_t)wq % 4) == 0, SGLK_ERR_INVALID, "mxfp4_scaled_mm: weights must be 4-byte aligned");
+    const DenseWs w = plan_dense(M, N, K, false, false);
+    SGLK_REQUIRE(workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "mxfp4_scaled_mm: workspace %zu < required %zu",
+                 workspace_bytes, w.total);
+    if (M == 0) return SGLK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    int4* tile_info = (int4*)(ws + w.tile_info);
+    int* num_tiles = (int*)(ws + w.num_tiles);
+    const int tiles = (int)ceil_div(M, kGenericTileM);
+    int rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
+    if (rc != SGLK_OK) return rc;
+    GenericGemmParams g{};
+    g.x = x;
+    g.x_type = SGLK_W_BF16;
+    g.x_stride = x_stride;
+    g.topk = 1;
+    g.gather = GG_GATHER_NONE;
+    g.tile_info = tile_info;
+    g.num_tiles = num_tiles;
+    g.n_tiles = (int)ceil_div(N, 64);
+    g.w = wq;
+    g.w_type = SGLK_W_MXFP4;
+    g.packed = 0;
+    g.C = K;
+    g.w_scale = (const float*)scales;   // E8M0 bytes; the kernel reads them as such
+    g.block_n = scale_packed ? 1 : 0;   // their layout
+    g.scale_rows = N;
+    g.scale_cols = K / 32;
+    g.n_out = N;
+    g.out = out;
+    g.out_type = SGLK_OUT_BF16;
+    g.out_stride = out_stride;
+    g.bias = bias;
+    g.ksplit = generic_ksplit(M, N, K);
+    if (g.ksplit > 1) {
+        const int stages = (int)ceil_div(K, 64);
+        int per = (int)ceil_div(stages, g.ksplit);
+        per += per & 1;
+        g.split_stages = per;
+        g.ksplit = (int)ceil_div(stages, per);
+        g.split_rows = M;
+        g.partial = (float*)(ws + w.partial);
+    }
+    return launch_gemm_generic(GG_PLAIN, g, tiles, s);
+}

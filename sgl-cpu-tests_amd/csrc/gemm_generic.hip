@@ -68,6 +68,27 @@ SGLK_DEV uint4 load8_as_bf16(const unsigned char* row_base, int k, int C) {
     return out;
 }
 
+// MX-fp4 (/root/reference/test_mxfp4.py:14-127): 8 consecutive E2M1 values of one row (4 bytes, element 2i in the low
+// nibble of byte i) times the row's E8M0 block scale 2^(s-127) of the 32-wide block -> 8 bf16.  Exact: an E2M1 value has
+// two significant bits and the scale is a power of two (v_cvt_scalef32_pk_bf16_fp4 does both in one instruction).
+// scales: [R][C/32] row-major, or (scale_packed) the reference's convert_scale_packed order [R/32][C/32][32].
+SGLK_DEV uint4 load8_mxfp4(const unsigned char* row_base, const unsigned char* scales, int scale_packed, int row, int k, int C) {
+    if (k >= C) return make_uint4(0, 0, 0, 0);
+    const unsigned raw = *reinterpret_cast<const unsigned*>(row_base + (k >> 1));
+    const int kb = k >> 5, nkb = C >> 5;
+    const int64_t si = scale_packed ? ((int64_t)(row >> 5) * nkb + kb) * 32 + (row & 31) : (int64_t)row * nkb + kb;
+    const unsigned sb = scales[si];
+    const float sc = __uint_as_float(sb ? sb << 23 : 0x00400000u);   // 2^(sb-127); sb = 0 is the fp32 denormal 2^-127
+    const bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(raw, sc, 0);
+    const bf16x2 b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(raw, sc, 1);
+    const bf16x2 c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(raw, sc, 2);
+    const bf16x2 d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(raw, sc, 3);
+    uint4 out;
+    out.x = __builtin_bit_cast(unsigned, a); out.y = __builtin_bit_cast(unsigned, b);
+    out.z = __builtin_bit_cast(unsigned, c); out.w = __builtin_bit_cast(unsigned, d);
+    return out;
+}
+
 // the k-octet (row, k..k+7) of ONE packed matrix [R][C] (pack.hip orders) as 8 bf16; k % 8 == 0, k < C
 template <int TYPE>
 SGLK_DEV uint4 load_packed_octet(const unsigned char* mat, int row, int k, int C) {
@@ -139,7 +160,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
             x_base[i] = reinterpret_cast<const unsigned char*>(p.x) + xr * p.x_stride * XES;
         }
         w_row[i] = weight_row(r);
-        w_base[i] = (w_row[i] >= 0 && !p.packed) ? wexp + (int64_t)w_row[i] * C * WES : nullptr;
+        if (WTYPE == SGLK_W_MXFP4) w_base[i] = w_row[i] >= 0 ? wexp + (int64_t)w_row[i] * (C >> 1) : nullptr;
+        else w_base[i] = (w_row[i] >= 0 && !p.packed) ? wexp + (int64_t)w_row[i] * C * WES : nullptr;
     }
 
     // ---- fragment read offsets --------------------------------------------------------------------------------------
@@ -182,6 +204,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
             xv[i] = x_base[i] ? load8_as_bf16<XTYPE>(x_base[i], k, C) : make_uint4(0, 0, 0, 0);
             if (w_row[i] < 0) {
                 wv[i] = make_uint4(0, 0, 0, 0);
+            } else if (WTYPE == SGLK_W_MXFP4) {   // p.w_scale = the E8M0 bytes, p.block_n = their layout flag
+                wv[i] = load8_mxfp4(w_base[i], reinterpret_cast<const unsigned char*>(p.w_scale), p.block_n, w_row[i], k, C);
             } else if (p.packed) {
                 // packed shapes have C % 64 == 0 (fp8/int8) or C % 8 == 0 (bf16): octets are complete
                 wv[i] = (k < C) ? load_packed_octet<WTYPE>(wexp, w_row[i], k, C) : make_uint4(0, 0, 0, 0);
@@ -353,6 +377,7 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
     if (p.w_type == SGLK_W_BF16 && p.x_type == SGLK_W_BF16) GG_MODES(SGLK_W_BF16, SGLK_W_BF16);
     else if (p.w_type == SGLK_W_FP8_E4M3 && p.x_type == SGLK_W_BF16) GG_MODES(SGLK_W_FP8_E4M3, SGLK_W_BF16);
     else if (p.w_type == SGLK_W_INT8 && p.x_type == SGLK_W_INT8) GG_MODES(SGLK_W_INT8, SGLK_W_INT8);
+    else if (p.w_type == SGLK_W_MXFP4 && p.x_type == SGLK_W_BF16 && mode == GG_PLAIN) GG_LAUNCH(SGLK_W_MXFP4, SGLK_W_BF16, GG_PLAIN);
     else SGLK_FAIL(SGLK_ERR_INVALID, "gemm_generic: unsupported operand types w=%d x=%d", p.w_type, p.x_type);
 #undef GG_MODES
 #undef GG_LAUNCH

@@ -96,6 +96,10 @@ def _packed_bits(is_vnni, shape1, shape2, dtype):
 
 
 def convert_weight_packed(weight):
+    if weight.dtype == torch.uint8:
+        # MX-fp4 nibble pairs [N, K/2] (/root/reference/test_mxfp4.py:160,183): the W4A16 kernel reads them row-major,
+        # only the scales have a packed order (convert_scale_packed)
+        return weight.contiguous().clone()
     if weight.dtype not in _WTYPE:
         raise RuntimeError(f"convert_weight_packed: unsupported dtype {weight.dtype}")
     if weight.dim() not in (2, 3):
@@ -694,6 +698,50 @@ def extend_attention_cpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         b_start_loc_extend=start.data_ptr(), B=B, HQ=HQ, HKV=HKV, HBUF=k_buffer.shape[1], D=D, DV=DV,
         max_len_extend=int(max_len_extend), sm_scale=float(sm_scale), logit_cap=float(logit_cap))
     _lib.check(_lib.lib().sglk_extend_attention(ctypes.byref(args), _stream(q_extend)), "extend_attention_cpu")
+
+
+# MX-fp4 W4A16 GEMM: convert_scale_packed, mxfp4_scaled_mm_cpu   /root/reference/test_mxfp4.py:5-7,160-171,183-202
+_DEF.define("convert_scale_packed(Tensor scale) -> Tensor")
+_DEF.define("mxfp4_scaled_mm_cpu(Tensor x, Tensor weight, Tensor scale, Tensor? bias, bool is_vnni) -> Tensor")
+
+
+def convert_scale_packed(scale):
+    """E8M0 scales [N, K/32] -> the order the reference checks (/root/reference/test_mxfp4.py:186): [N/32][K/32][32],
+    returned with the input's shape.  N not a multiple of 32: unchanged (the GEMM then reads them row-major)."""
+    if scale.dim() != 2 or scale.dtype != torch.uint8:
+        raise RuntimeError("convert_scale_packed: expect a 2-D uint8 [N, K/32] tensor of E8M0 scales")
+    n, kb = scale.shape
+    if n % 32 != 0:
+        return scale.contiguous().clone()
+    return scale.view(n // 32, 32, kb).transpose(1, 2).contiguous().view(n, kb)
+
+
+def mxfp4_scaled_mm_cpu(x, weight, scale, bias, is_vnni):
+    if x.dim() != 2 or x.dtype != torch.bfloat16 or x.stride(1) != 1:
+        raise RuntimeError("mxfp4_scaled_mm_cpu: x must be a 2-D bfloat16 tensor with a contiguous last dim")
+    if weight.dim() != 2 or weight.dtype != torch.uint8 or scale.dim() != 2 or scale.dtype != torch.uint8:
+        raise RuntimeError("mxfp4_scaled_mm_cpu: weight [N, K/2] and scale [N, K/32] must be uint8")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] * 2 != K or K % 32 != 0 or tuple(scale.shape) != (N, K // 32):
+        raise RuntimeError(f"mxfp4_scaled_mm_cpu: x {tuple(x.shape)}, weight {tuple(weight.shape)}, scale "
+                           f"{tuple(scale.shape)} do not describe [M, K] x [N, K/2] with one scale per 32 (K % 32 == 0)")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N):
+        raise RuntimeError("mxfp4_scaled_mm_cpu: bias must be float32 [N]")
+    w = weight.contiguous()
+    sc = scale.contiguous()
+    b = bias.contiguous() if bias is not None else None
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    L = _lib.lib()
+    ws = _workspace(L.sglk_scaled_mm_workspace_bytes(M, N, K, _lib.W_BF16, 0), x.device)
+    _lib.check(L.sglk_mxfp4_scaled_mm(_ptr(x), x.stride(0), _ptr(w), _ptr(sc), 1 if (is_vnni and N % 32 == 0) else 0,
+                                      _ptr(b) if b is not None else None, _ptr(out), out.stride(0), M, N, K, _ptr(ws),
+                                      ws.numel(), _stream(x)), "mxfp4_scaled_mm_cpu")
+    return out
+
+
+_impl("convert_scale_packed", convert_scale_packed)
+_impl("mxfp4_scaled_mm_cpu", mxfp4_scaled_mm_cpu)
 
 
 # bmm_cpu: /root/reference/test_bmm_fp8.py:38-39,67,73 -- out[b] = mat1[b] @ mat2[b]^T, bf16, strided out / mat1 views

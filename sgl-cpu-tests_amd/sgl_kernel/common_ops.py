@@ -20,3 +20,5 @@ biased_grouped_topk_cpu = torch.ops.sgl_kernel.biased_grouped_topk_cpu
 qkv_proj_with_rope = torch.ops.sgl_kernel.qkv_proj_with_rope
 flash_attn_varlen_func = torch.ops.sgl_kernel.flash_attn_varlen_func
 bmm_cpu = torch.ops.sgl_kernel.bmm_cpu
+convert_scale_packed = torch.ops.sgl_kernel.convert_scale_packed
+mxfp4_scaled_mm_cpu = torch.ops.sgl_kernel.mxfp4_scaled_mm_cpu

@@ -42,10 +42,10 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def lift(path, names, extra_globals=None):
-    """Compile the named top-level FunctionDefs of a reference file into a fresh namespace."""
+    """Compile the named top-level FunctionDefs / ClassDefs of a reference file into a fresh namespace."""
     src = open(os.path.join(REF, path)).read()
     tree = ast.parse(src)
-    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
     missing = set(names) - {n.name for n in keep}
     if missing:
         raise RuntimeError(f"{path}: functions not found: {missing}")
@@ -319,8 +319,23 @@ def gen_bmm():
              dict(B=B, M=M, N=N, K=K, seed=seed, input_sha256=checksum(inp["mat1"].contiguous(), inp["mat2"])))
 
 
+def gen_mxfp4():
+    """mxfp4_scaled_mm_cpu: MXFP4QuantizeUtil (quantize / dequantize) of /root/reference/test_mxfp4.py:14-127 and the
+    expectation matmul(A.float(), Bdq.float().t()).bfloat16() (+ bias) of :166-168,196-198."""
+    ns = lift("test_mxfp4.py", ["MXFP4QuantizeUtil"], {"block_size": 32})
+    util = ns["MXFP4QuantizeUtil"]
+    for name, M, N, K, kind, has_bias, seed in recipes.MXFP4_CASES:
+        inp = recipes.mxfp4_inputs(M, N, K, kind, has_bias, seed, util.quantize)
+        dq = util.dequantize(inp["wq"], torch.bfloat16, inp["ws"])
+        ref = torch.matmul(inp["a"].float(), dq.float().t()).bfloat16()
+        if inp["bias"] is not None:
+            ref.add_(inp["bias"].view(1, -1))
+        tensors = {"ref_out": ref, "dq": dq.contiguous(), "wq": inp["wq"], "ws": inp["ws"]}
+        save("mxfp4_" + name, tensors, dict(M=M, N=N, K=K, kind=kind, seed=seed, input_sha256=checksum(inp["a"], inp["wq"], inp["ws"])))
+
+
 FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
-            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen, "bmm": gen_bmm}
+            "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen, "bmm": gen_bmm, "mxfp4": gen_mxfp4}
 
 
 if __name__ == "__main__":

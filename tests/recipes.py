@@ -397,3 +397,31 @@ def bmm_inputs(B, M, N, K, chunk, seed):
     mat2 = torch.randn(B, N, K, generator=g).to(bf)
     out = torch.zeros(M, B, N + pad, dtype=bf).narrow(2, 0, N).transpose(0, 1)
     return dict(mat1=mat1, mat2=mat2, out=out)
+
+
+# name, M, N, K, kind, bias, seed    (/root/reference/test_mxfp4.py:206-210; "quant" = weights quantised from floats (:150-157),
+# "raw" = random nibbles with scale bytes 126 (:178-181); the last two widen the scale range and the row count)
+MXFP4_CASES = [
+    ("m1_n32_k32_quant", 1, 32, 32, "quant", False, 9701),
+    ("m1_n32_k2048_quant", 1, 32, 2048, "quant", False, 9702),
+    ("m112_n960_k352_raw", 112, 960, 352, "raw", False, 9703),
+    ("m2_n128_k128_raw_bias", 2, 128, 128, "raw", True, 9704),
+    ("m11_n64_k96_raw", 11, 64, 96, "raw", False, 9705),
+    ("m300_n256_k512_wide_bias", 300, 256, 512, "wide", True, 9706),
+]
+
+
+def mxfp4_inputs(M, N, K, kind, has_bias, seed, quantize=None):
+    """/root/reference/test_mxfp4.py:146-164,174-194.  `quantize` = the MX-fp4 quantiser for kind "quant" (the golden
+    generator passes the reference's, tests pass the oracle's restatement; the golden file also stores wq / ws)."""
+    g = _gen(seed)
+    a = (torch.randn(M, K, generator=g) / 10).to(torch.bfloat16)
+    if kind == "quant":
+        b = ((torch.rand(N, K, generator=g) - 0.5) * 2).to(torch.bfloat16) * 1e-2
+        wq, ws = quantize(b)
+    else:
+        wq = torch.randint(0, 256, (N, K // 2), generator=g, dtype=torch.uint8)
+        lo, hi = (126, 127) if kind == "raw" else (110, 131)
+        ws = torch.randint(lo, hi, (N, K // 32), generator=g, dtype=torch.uint8)
+    bias = torch.randn(N, generator=g) if has_bias else None
+    return dict(a=a, wq=wq, ws=ws.view(N, K // 32), bias=bias)

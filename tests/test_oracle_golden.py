@@ -277,6 +277,19 @@ def test_oracle_bmm(case):
     assert moe.allclose_ref(g["ref_out"], ogemm.bmm(inp["mat1"], inp["mat2"]).bfloat16())
 
 
+@pytest.mark.parametrize("case", recipes.MXFP4_CASES, ids=lambda c: c[0])
+def test_oracle_mxfp4(case):
+    """oracle/gemm.py's MX-fp4 quantiser, dequantiser and GEMM against the reference's MXFP4QuantizeUtil outputs."""
+    from oracle import gemm as ogemm
+    name, M, N, K, kind, has_bias, seed = case
+    g, _ = load_golden("mxfp4_" + name)
+    inp = recipes.mxfp4_inputs(M, N, K, kind, has_bias, seed, ogemm.mxfp4_quantize)
+    assert torch.equal(inp["wq"], g["wq"]) and torch.equal(inp["ws"], g["ws"])          # quantiser, bit-exact
+    assert torch.equal(ogemm.mxfp4_dequant(inp["wq"], inp["ws"]).bfloat16(), g["dq"])    # dequantiser, bit-exact
+    out = ogemm.mxfp4_scaled_mm(inp["a"], inp["wq"], inp["ws"], inp["bias"])
+    assert moe.allclose_ref(g["ref_out"], out.bfloat16())
+
+
 # ---- qkv_proj_with_rope (oracle/absorb.py vs the reference's native_torch / native_torch_int8) --------------------------
 @pytest.mark.parametrize("case", recipes.ABSORB_CASES, ids=lambda c: c[0])
 def test_absorb_oracle_matches_reference_oracle(case):

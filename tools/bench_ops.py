@@ -182,6 +182,28 @@ def bench_gemm():
                  roofline_frac=round(flop / ms / 1e9 / peak, 4), peak_tflops=peak, bound="mfma")
 
 
+def bench_mxfp4():
+    """mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py): W4A16, weights expanded to bf16 in the loader.  Small M is bound
+    by the weight bytes (N*K/2 + scales), large M by the bf16 matrix cores; bmm_cpu rides along (test_bmm_fp8.py:131-132)."""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for (M, N, K) in ((1, 4096, 4096), (16, 4096, 4096), (128, 4096, 4096), (1024, 12288, 2048)):
+        x = (torch.randn(M, K, device="cuda", generator=g) / 10).bfloat16()
+        wq = torch.randint(0, 256, (N, K // 2), device="cuda", generator=g, dtype=torch.uint8)
+        ws = torch.randint(120, 128, (N, K // 32), device="cuda", generator=g, dtype=torch.uint8)
+        sp = ops.convert_scale_packed(ws)
+        ms = timed(lambda i: ops.mxfp4_scaled_mm_cpu(x, wq, sp, None, True), 20)
+        byts, flop = N * K // 2 + N * K // 32 + 2 * M * (N + K), 2 * M * N * K
+        t_hbm, t_mfma = byts / (PEAK_HBM * 1e9), flop / (PEAK_BF16 * 1e12)
+        emit(op="mxfp4_scaled_mm", M=M, N=N, K=K, ms=round(ms, 4), tflops=round(flop / ms / 1e9, 2), gbps=round(byts / ms / 1e6, 1),
+             bound="hbm" if t_hbm > t_mfma else "mfma", roofline_frac=round(max(t_hbm, t_mfma) * 1e3 / ms, 4))
+    for (B, M, N, K) in ((16, 1, 512, 128), (16, 1, 128, 512), (16, 64, 512, 128)):
+        a = torch.randn(M, B, K + 64, device="cuda", generator=g).bfloat16().narrow(2, 0, K).transpose(0, 1)
+        w = ops.convert_weight_packed(torch.randn(B, N, K, device="cuda", generator=g).bfloat16())
+        out = torch.empty(M, B, N + 64, device="cuda", dtype=torch.bfloat16).narrow(2, 0, N).transpose(0, 1)
+        ms = timed(lambda i: ops.bmm_cpu(out, a, w, True, None), 20)
+        emit(op="bmm_cpu", B=B, M=M, N=N, K=K, ms=round(ms, 4), gbps=round(2 * B * N * K / ms / 1e6, 1), bound="launch")
+
+
 def bench_attn():
     g = torch.Generator(device="cuda").manual_seed(3)
     dt = torch.bfloat16
@@ -281,7 +303,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
