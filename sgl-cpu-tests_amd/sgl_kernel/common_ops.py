@@ -22,3 +22,6 @@ flash_attn_varlen_func = torch.ops.sgl_kernel.flash_attn_varlen_func
 bmm_cpu = torch.ops.sgl_kernel.bmm_cpu
 convert_scale_packed = torch.ops.sgl_kernel.convert_scale_packed
 mxfp4_scaled_mm_cpu = torch.ops.sgl_kernel.mxfp4_scaled_mm_cpu
+
+# tensor-parallel collectives (/root/reference/test_allreduce.py:82-87,103-105): RCCL / gloo through torch.distributed
+from .collectives import initialize, shm_allgather, shm_allreduce  # noqa: E402,F401
