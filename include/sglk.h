@@ -172,6 +172,12 @@ typedef struct {
 size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
 int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
 
+/* Expert-parallel combine (no reference counterpart: the exchange around fused_experts):
+ * out[m][:] = sum over d = 0..G-1 ascending of rows[table[m*G + d]][:] for table entries >= 0; bf16 rows, fp32 sum, one
+ * bf16 rounding.  K % 8 == 0, strides in elements (multiples of 8). */
+int sglk_ep_reduce_rows(const void* rows, int64_t rows_stride, const int32_t* table, int32_t G, void* out,
+                        int64_t out_stride, int32_t M, int32_t K, void* stream);
+
 /* mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py:148,170,201): out[M][N] bf16 = x[M][K] bf16 . dequant(wq, scales)^T
  * (+ bias f32 [N]).  wq uint8 [N][K/2], element 2i of a row in the low nibble of byte i (E2M1: sign, 2-bit exponent,
  * 1-bit mantissa -> 0, 0.5, 1, 1.5, 2, 3, 4, 6); scales uint8 E8M0 (2^(s-127)) per 32 consecutive k: [N][K/32] row-major,

@@ -119,6 +119,37 @@ __global__ __launch_bounds__(256) void moe_combine_scalar_kernel(const uint16_t*
     }
 }
 
+// Expert-parallel combine (sgl_kernel/expert_parallel.py): out[m] = sum over ranks d ascending of rows[table[m][d]]
+// (table entry < 0: rank d returned nothing for token m), fp32 sum, one bf16 rounding -- the same fixed order as the
+// single-GPU combine, so a run is bit-reproducible.  One 16-byte chunk of one token per thread and iteration.
+__global__ __launch_bounds__(256) void ep_reduce_rows_kernel(const uint16_t* __restrict__ rows, int64_t rows_stride,
+                                                             const int32_t* __restrict__ table, int G,
+                                                             uint16_t* __restrict__ out, int64_t out_stride, int M, int K) {
+    const int chunks_per_row = K >> 3;
+    const int64_t total = (int64_t)M * chunks_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks_per_row);
+        const int c = (int)(i - (int64_t)m * chunks_per_row);
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < G; ++d) {
+            const int idx = table[(int64_t)m * G + d];
+            if (idx < 0) continue;
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rows + (int64_t)idx * rows_stride + c * 8));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sum[2 * q] += __uint_as_float(v[q] << 16);
+                sum[2 * q + 1] += __uint_as_float(v[q] & 0xffff0000u);
+            }
+        }
+        u32x4 o;
+        o[0] = pack_bf16x2(sum[0], sum[1]);
+        o[1] = pack_bf16x2(sum[2], sum[3]);
+        o[2] = pack_bf16x2(sum[4], sum[5]);
+        o[3] = pack_bf16x2(sum[6], sum[7]);
+        *reinterpret_cast<u32x4*>(out + (int64_t)m * out_stride + c * 8) = o;
+    }
+}
+
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
                        int K, int E, int topk, hipStream_t stream) {
     if (M == 0) return SGLK_OK;
@@ -147,3 +178,20 @@ int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* o
 }
 
 }  // namespace sglk
+
+extern "C" int sglk_ep_reduce_rows(const void* rows, int64_t rows_stride, const int32_t* table, int32_t G, void* out,
+                                   int64_t out_stride, int32_t M, int32_t K, void* stream) {
+    using namespace sglk;
+    SGLK_REQUIRE(M >= 0 && K > 0 && G > 0, SGLK_ERR_INVALID, "ep_reduce_rows: bad sizes M=%d K=%d G=%d", M, K, G);
+    if (M == 0) return SGLK_OK;
+    SGLK_REQUIRE(rows && table && out, SGLK_ERR_INVALID, "ep_reduce_rows: null pointer");
+    SGLK_REQUIRE(K % 8 == 0 && rows_stride % 8 == 0 && out_stride % 8 == 0 && ((uintptr_t)rows % 16) == 0 &&
+                     ((uintptr_t)out % 16) == 0, SGLK_ERR_SHAPE, "ep_reduce_rows: rows must be 16-byte aligned, K %% 8 == 0");
+    int64_t blocks = ceil_div((int64_t)M * (K >> 3), 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(ep_reduce_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)rows,
+                       rows_stride, table, G, (uint16_t*)out, out_stride, M, K);
+    SGLK_CHECK_LAUNCH("ep_reduce_rows");
+    return SGLK_OK;
+}
+

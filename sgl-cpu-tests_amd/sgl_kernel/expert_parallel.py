@@ -87,17 +87,34 @@ class ExpertParallelMoE:
         back = torch.empty(rows.shape[0], K, dtype=hidden.dtype, device=hidden.device)
         self._all_to_all(back, partial.contiguous(), send_l, recv_l)
 
-        # fixed-order reduce: segment d holds at most one row per token, segments are added in rank order
-        out = torch.zeros(M, K, dtype=torch.float32, device=hidden.device)
+        # fixed-order reduce: segment d of `back` holds at most one row per token; rows are added per token in rank
+        # order in fp32 and rounded once
+        out = self._reduce(back, send_tok, send_rank, send_l, M)
+        self.last_stats = dict(rows_sent=int(sum(send_l)), rows_received=int(R_recv),
+                               bytes_sent=int(sum(send_l)) * K * hidden.element_size())
+        return out
+
+    def _reduce(self, back, send_tok, send_rank, send_l, M):
+        G, K = self.world, back.shape[1]
+        if back.is_cuda and back.dtype == torch.bfloat16 and K % 8 == 0:
+            # one HIP launch: table[m][d] = row of `back` that rank d returned for token m (-1: none)
+            from . import _lib
+            table = torch.full((M, G), -1, dtype=torch.int32, device=back.device)
+            table[send_tok, send_rank] = torch.arange(back.shape[0], dtype=torch.int32, device=back.device)
+            out = torch.empty(M, K, dtype=back.dtype, device=back.device)
+            _lib.check(_lib.lib().sglk_ep_reduce_rows(back.data_ptr(), back.stride(0), table.data_ptr(), G, out.data_ptr(),
+                                                      out.stride(0), M, K, torch.cuda.current_stream(back.device).cuda_stream),
+                       "ep_reduce_rows")
+            return out
+        # host tensors (the gloo tests of the exchange logic): the same sums, same order, in torch
+        out = torch.zeros(M, K, dtype=torch.float32, device=back.device)
         off = 0
         for d in range(G):
             n = send_l[d]
             if n:
                 out.index_add_(0, send_tok[off:off + n], back[off:off + n].float())
             off += n
-        self.last_stats = dict(rows_sent=int(sum(send_l)), rows_received=int(R_recv),
-                               bytes_sent=int(sum(send_l)) * K * hidden.element_size())
-        return out.to(hidden.dtype)
+        return out.to(back.dtype)
 
 
 def masked_allgather_reference(hidden, topk_weights, topk_ids, num_experts, local_experts_fn, group=None):
