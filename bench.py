@@ -150,14 +150,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    # N > 1: consecutive steps alternate between two HIP streams, so that step i+1's routing plan, row gathers and dispatch
+    # all-to-all overlap step i's experts and combine (every step still does all of its work; the stage workspaces are per
+    # stream).  SGLK_EP_STREAMS=1 runs them back to back on one stream.
+    n_streams = int(os.environ.get("SGLK_EP_STREAMS", "2" if (world > 1 and backend == "nccl") else "1"))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if (world > 1 and n_streams > 1) else None
+
+    def run_steps(n):
+        if streams is None:
+            for _ in range(n):
+                step()
+            return
+        cur = torch.cuda.current_stream()
+        for i in range(n):
+            st = streams[i % len(streams)]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                step()
+        for st in streams:
+            cur.wait_stream(st)
+
+    run_steps(args.warmup)
     barrier()
     _ops.set_stage_timer(timer)
     L.sglk_stage_timer_reset(timer)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -199,7 +217,9 @@ def main():
                                    f"inplace=False, {LCLONES} rotating weight/input clones",
                        "tokens_per_gpu": M, "experts_per_gpu": E_local,
                        "parallelism": "single GPU" if world == 1 else
-                       (f"ep{world} (RCCL all-to-all dispatch/combine)" if backend == "nccl" else
+                       (f"ep{world} (RCCL all-to-all dispatch/combine" +
+                        (f", {len(streams)} steps in flight on separate HIP streams)" if streams else ")")
+                        if backend == "nccl" else
                         f"ep{world} REHEARSAL over {backend}, host-staged payloads, ranks sharing GPUs: not a measurement")},
             "roofline": {"bound": "mfma", "kernel": "g256i::moe_gemm_fp8w_256i_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
                          "achieved": round(gemm1_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
