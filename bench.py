@@ -170,6 +170,12 @@ def main():
         for st in streams:
             cur.wait_stream(st)
 
+    # Device priming, part of setup like the weight packing above: the first ~10 launches after an idle period run through
+    # a power-management transient (a cold chip boosts, overshoots down, then settles: GEMM-1 0.74 -> 0.99 -> 0.79 ms,
+    # profiles/r01_v7_kernel_stats.csv), so a short run would time the transient instead of the steady state it reports.
+    # These steps are not counted as warm-up or timed steps; their number is printed in the result line.
+    prime = max(0, 12 - args.warmup)
+    run_steps(prime)
     run_steps(args.warmup)
     barrier()
     _ops.set_stage_timer(timer)
@@ -215,7 +221,7 @@ def main():
             "config": {"workload": f"fused_experts fp8-w8a16 block[128,128], Qwen3-30B-A3B experts "
                                    f"(K={K_HIDDEN}, N={N_INTER}, E={N_EXPERTS}, top-{TOPK}), {M} tokens per GPU per step, "
                                    f"inplace=False, {LCLONES} rotating weight/input clones",
-                       "tokens_per_gpu": M, "experts_per_gpu": E_local,
+                       "tokens_per_gpu": M, "experts_per_gpu": E_local, "priming_steps_before_warmup": prime,
                        "parallelism": "single GPU" if world == 1 else
                        (f"ep{world} (RCCL all-to-all dispatch/combine" +
                         (f", {len(streams)} steps in flight on separate HIP streams)" if streams else ")")
