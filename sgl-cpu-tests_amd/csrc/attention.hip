@@ -505,6 +505,29 @@ struct TileDma {
     static constexpr int CH = WIDTH / 8;
     static constexpr int N = (kKeys * CH + 255) / 256;   // DMA instructions per wave per tile
     static_assert((kKeys * CH) % 256 == 0, "the image must be a whole number of 4-wave DMA rounds (head dim % 32 == 0)");
+    // The page lookups of a tile and its DMA instructions are issued one loop iteration apart (decode kernel): loads
+    // retire in order, so a lookup issued behind DMA instructions cannot be consumed before those have landed -- with both in
+    // one call a tile cost three to four memory round trips before its last row was even requested.
+    SGLK_DEV static void lookup(int (&tok)[N], const KvSource& src, int p0, int nkeys, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = i * 256 + wave * 64 + lane;
+            const int row = c / CH;
+            const int rr = row < nkeys ? row : nkeys - 1;
+            tok[i] = src.page_is64 ? (int)reinterpret_cast<const int64_t*>(src.page)[p0 + rr]
+                                   : reinterpret_cast<const int*>(src.page)[p0 + rr];
+        }
+    }
+    SGLK_DEV static void issue_rows(unsigned char* lds, const KvSource& src, const int (&tok)[N], int wave, int lane) {
+        constexpr int MASK = Swz<CH>::mask;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = i * 256 + wave * 64 + lane;
+            const int row = c / CH, slot = c - row * CH;
+            const unsigned short* g = src.buf + (int64_t)tok[i] * src.buf_stride_tok + ((slot ^ (row & MASK)) << 3);
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    }
     SGLK_DEV static void issue(unsigned char* lds, const KvSource& src, int p0, int nkeys, int wave, int lane) {
         constexpr int MASK = Swz<CH>::mask;
         constexpr int HALF = (N + 1) / 2;
@@ -578,14 +601,40 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
         TileDma<D>::issue(buf, ks, p0, nk, wave, lane);
         if (!V_ALIAS) TileDma<DV>::issue(buf + KB, vs, p0, nk, wave, lane);
     };
-    if (ntiles > 0) issue(0, dyn_lds);
+    // double-buffered form: the cache rows (page lookups) of tile t+2 are fetched while tile t+1's rows fly and tile t is
+    // multiplied; K and V rows of a key share the lookup only when their chunk maps agree (D == DV)
+    int tokk[TileDma<D>::N], tokv[V_ALIAS ? 1 : TileDma<DV>::N];
+    auto lookup = [&](int t) {
+        const int tt = t < ntiles ? t : ntiles - 1;          // past the end: re-read the last tile's ids (never used)
+        const int p0 = k_begin + tt * kKeys;
+        const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
+        TileDma<D>::lookup(tokk, ks, p0, nk, wave, lane);
+        if constexpr (!V_ALIAS) TileDma<DV>::lookup(tokv, vs, p0, nk, wave, lane);
+    };
+    auto issue_rows = [&](unsigned char* buf) {
+        TileDma<D>::issue_rows(buf, ks, tokk, wave, lane);
+        if constexpr (!V_ALIAS) TileDma<DV>::issue_rows(buf + KB, vs, tokv, wave, lane);
+    };
+    if (ntiles > 0) {
+        if (kDouble) {
+            lookup(0);
+            issue_rows(dyn_lds);
+            lookup(1);
+        } else {
+            issue(0, dyn_lds);
+        }
+    }
     for (int t = 0; t < ntiles; ++t) {
         unsigned char* cur = dyn_lds + (kDouble ? (t & 1) * (KB + VB) : 0);
         if (kDouble) {
-            // every wave has left tile t-1 (whose buffer tile t+1 overwrites) before anyone passes this barrier
+            // every wave has left tile t-1 (whose buffer tile t+1 overwrites) before anyone passes this barrier; the wait
+            // also covers the lookups of tile t+1, issued right behind tile t's rows
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t + 1 < ntiles) issue(t + 1, dyn_lds + ((t + 1) & 1) * (KB + VB));
+            if (t + 1 < ntiles) {
+                issue_rows(dyn_lds + ((t + 1) & 1) * (KB + VB));
+                lookup(t + 2);
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
