@@ -159,30 +159,31 @@ struct Core {
     // with position < limit; V_ALIAS: V rows live in the K image (row width D), else in its own image (row width DV)
     // DV here is the width of the V slice this wave accumulates; dv0 = its first column inside the V image, whose rows
     // are VROW elements wide (0 = DV, i.e. the wave owns the whole width)
-    template <bool V_ALIAS, int VROW = 0>
+    // NKT = 16-key tiles this wave takes from the image (4 = all 64 keys; 2 = the 32 keys from row k0, decode kernel)
+    template <bool V_ALIAS, int VROW = 0, int NKT = 4>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
-                       float scale_log2e, float logit_cap, int lane, int dv0 = 0) {
+                       float scale_log2e, float logit_cap, int lane, int dv0 = 0, int k0 = 0) {
         int lim_min = limit[0];
 #pragma unroll
         for (int qt = 1; qt < QT; ++qt) lim_min = limit[qt] < lim_min ? limit[qt] : lim_min;
-        const bool masked = __any(key_base + kKeys > lim_min);
+        const bool masked = __any(key_base + k0 + NKT * 16 > lim_min);
         const bool capped = __builtin_amdgcn_readfirstlane(logit_cap > 0.f);
         constexpr int KMASK = Swz<KCH>::mask;
         constexpr int VW = V_ALIAS ? D : (VROW ? VROW : DV);   // row width of the image V is read from
         constexpr int VMASK = V_ALIAS ? KMASK : Swz<VW / 8>::mask;
         constexpr float kRescaleThr = 8.0f;                  // log2 units: P <= 2^8 before a rescale is forced
         const int r = lane & 15, g = lane >> 4;
-        f32x4 s[QT][4];
+        f32x4 s[QT][NKT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < NKT; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // ---- S^T = K . Q^T ----
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int row = kt * 16 + r;
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int row = k0 + kt * 16 + r;
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(klds + row * (D * 2) + (((ks * 4 + g) ^ (row & KMASK)) << 4));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt)
@@ -190,7 +191,7 @@ struct Core {
             }
         }
         // ---- online softmax per column (lane) ----
-        bf16x8 pf[QT][2];
+        bf16x8 pf[QT][NKT / 2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             // s holds RAW q.k; the softmax scale rides in the exp2 argument (one v_fma per element instead of a
@@ -199,7 +200,7 @@ struct Core {
             float sc = scale_log2e;
             if (capped) {
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         // cap * tanh(x / cap) on the natural-log-scale logit, stored in log2 units
@@ -210,16 +211,16 @@ struct Core {
             }
             if (masked) {
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int key = key_base + kt * 16 + g * 4 + j;
+                        const int key = key_base + k0 + kt * 16 + g * 4 + j;
                         s[qt][kt][j] = key < limit[qt] ? s[qt][kt][j] : -INFINITY;
                     }
             }
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qt][kt][j]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -239,9 +240,9 @@ struct Core {
             }
             const float neg_m = (m_new == -INFINITY) ? 0.f : -m_new;
             float psum = 0.f;
-            float p[4][4];
+            float p[NKT][4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     p[kt][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][kt][j], sc, neg_m));   // exp2(-inf) = 0 for masked keys
@@ -249,7 +250,7 @@ struct Core {
                 }
             l[qt] += psum;     // per-lane partial (this lane's keys); lane groups are summed at the end
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
+            for (int ss = 0; ss < NKT / 2; ++ss) {
                 u32x4 w;
                 w[0] = pack_bf16x2(p[2 * ss][0], p[2 * ss][1]);
                 w[1] = pack_bf16x2(p[2 * ss][2], p[2 * ss][3]);
@@ -263,8 +264,8 @@ struct Core {
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const int row0 = ss * 32 + g * 4 + q;
+            for (int ss = 0; ss < NKT / 2; ++ss) {
+                const int row0 = k0 + ss * 32 + g * 4 + q;
                 const int row1 = row0 + 16;
                 const int col = dv0 + t * 16 + pp * 4;      // in elements; 4 elements = 8 bytes inside one 16-B chunk
                 const int ch = col >> 3, sub = (col & 7) * 2;
@@ -500,18 +501,18 @@ typedef __attribute__((address_space(3))) void* dma_lptr_t;
 // instruction, and the 16-byte-chunk swizzle is applied to the SOURCE address.  Rows past `nkeys` re-read the last valid
 // row (finite data: their probabilities are exactly 0, but 0 * garbage must not be NaN).  Returns nothing to wait on:
 // the caller counts the instructions (kDmaPerThread) in its s_waitcnt vmcnt.
-template <int WIDTH>
+template <int WIDTH, int THREADS>   // THREADS = the decode kernel's workgroup size (256 or 512)
 struct TileDma {
     static constexpr int CH = WIDTH / 8;
-    static constexpr int N = (kKeys * CH + 255) / 256;   // DMA instructions per wave per tile
-    static_assert((kKeys * CH) % 256 == 0, "the image must be a whole number of 4-wave DMA rounds (head dim % 32 == 0)");
+    static constexpr int N = (kKeys * CH + THREADS - 1) / THREADS;   // DMA instructions per wave per tile
+    static_assert((kKeys * CH) % THREADS == 0, "the image must be a whole number of workgroup-wide DMA rounds");
     // The page lookups of a tile and its DMA instructions are issued one loop iteration apart (decode kernel): loads
     // retire in order, so a lookup issued behind DMA instructions cannot be consumed before those have landed -- with both in
     // one call a tile cost three to four memory round trips before its last row was even requested.
     SGLK_DEV static void lookup(int (&tok)[N], const KvSource& src, int p0, int nkeys, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int c = i * 256 + wave * 64 + lane;
+            const int c = i * THREADS + wave * 64 + lane;
             const int row = c / CH;
             const int rr = row < nkeys ? row : nkeys - 1;
             tok[i] = src.page_is64 ? (int)reinterpret_cast<const int64_t*>(src.page)[p0 + rr]
@@ -522,10 +523,10 @@ struct TileDma {
         constexpr int MASK = Swz<CH>::mask;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int c = i * 256 + wave * 64 + lane;
+            const int c = i * THREADS + wave * 64 + lane;
             const int row = c / CH, slot = c - row * CH;
             const unsigned short* g = src.buf + (int64_t)tok[i] * src.buf_stride_tok + ((slot ^ (row & MASK)) << 3);
-            __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * THREADS + wave * 64) * 16), 16, 0, 0);
         }
     }
     SGLK_DEV static void issue(unsigned char* lds, const KvSource& src, int p0, int nkeys, int wave, int lane) {
@@ -539,7 +540,7 @@ struct TileDma {
             for (int j = 0; j < HALF; ++j) {
                 const int i = h0 + j;
                 if (i < N) {
-                    const int c = i * 256 + wave * 64 + lane;        // linear chunk of the image this lane fills
+                    const int c = i * THREADS + wave * 64 + lane;        // linear chunk of the image this lane fills
                     const int row = c / CH, slot = c - row * CH;
                     const int rr = row < nkeys ? row : nkeys - 1;
                     g[j] = kv_row_paged(src, p0 + rr) + ((slot ^ (row & MASK)) << 3);
@@ -549,23 +550,30 @@ struct TileDma {
             for (int j = 0; j < HALF; ++j) {
                 const int i = h0 + j;
                 if (i < N)
-                    __builtin_amdgcn_global_load_lds((dma_gptr_t)g[j], (dma_lptr_t)(lds + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((dma_gptr_t)g[j], (dma_lptr_t)(lds + (i * THREADS + wave * 64) * 16), 16, 0, 0);
             }
         }
     }
 };
 
-// 4 waves = CT column tiles (16 q heads each) x NDV slices of the value width: every wave computes the logits of its
-// 16 heads against all 64 keys and accumulates DV / NDV output columns, so the accumulator of the widest case
-// (MLA, DV = 512, 22 heads -> CT = 2, NDV = 2) is 64 registers and nothing spills.  K/V tiles arrive by LDS-DMA, two
-// tiles deep when the images fit (tile t+1 flies while tile t is multiplied).
-template <int D, int DV, bool V_ALIAS, int NDV>
-__global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodeParams p) {
+// 8 waves = 2 key halves x CT column tiles (16 q heads each) x NDV slices of the value width (CT * NDV = 4): a wave computes
+// the logits of its 16 heads against ITS 32 keys of every 64-key tile and accumulates DV / NDV output columns over them --
+// an independent online-softmax state per wave; the two key halves of a (column tile, slice) are merged once, through LDS,
+// after the last tile.  (With 4 waves each taking all 64 keys the logits were computed NDV times over and one wave per SIMD
+// had nothing to hide its LDS reads and DMA issue behind.)  The accumulator of the widest case (MLA, DV = 512, 22 heads ->
+// CT = 2, NDV = 2) is 64 registers.  K/V tiles arrive by LDS-DMA, two tiles deep when the images fit (tile t+1 flies while
+// tile t is multiplied).
+// KH = 1: 4 waves, each takes all 64 keys of a tile (no merge) -- faster for narrow heads (D = 128: 4.6 vs 4.4 TB/s), where
+// the logits are a small part of the work and two workgroups share a CU anyway.
+template <int D, int DV, bool V_ALIAS, int NDV, int KH>
+__global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const DecodeParams p) {
+    typedef TileDma<D, 256 * KH> DmaK;
+    typedef TileDma<DV, 256 * KH> DmaV;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     constexpr int KB = kKeys * D * 2, VB = V_ALIAS ? 0 : kKeys * DV * 2;
     constexpr bool kDouble = 2 * (KB + VB) <= 150 * 1024;
     constexpr int DVW = DV / NDV;
-    constexpr int kDma = TileDma<D>::N + (V_ALIAS ? 0 : TileDma<DV>::N);
+    constexpr int kDma = DmaK::N + (V_ALIAS ? 0 : DmaV::N);
 
     const int b = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
     const int group = p.HQ / p.HKV;
@@ -574,7 +582,8 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
     const int k_begin = split * per;
     const int k_end = (k_begin + per < seq_len) ? k_begin + per : seq_len;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ct = wave / NDV, dsl = wave - ct * NDV;   // column tile, value slice
+    const int kh = KH == 2 ? wave >> 2 : 0, w4 = wave & 3;   // key half; (column tile, value slice) index
+    const int ct = w4 / NDV, dsl = w4 - ct * NDV;       // column tile, value slice
     const int col = ct * 16 + (lane & 15);              // q head inside the group handled by this lane's column
     const bool col_valid = col < group;
     const bool wave_active = ct * 16 < group;
@@ -598,22 +607,22 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
     auto issue = [&](int t, unsigned char* buf) {
         const int p0 = k_begin + t * kKeys;
         const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
-        TileDma<D>::issue(buf, ks, p0, nk, wave, lane);
-        if (!V_ALIAS) TileDma<DV>::issue(buf + KB, vs, p0, nk, wave, lane);
+        DmaK::issue(buf, ks, p0, nk, wave, lane);
+        if (!V_ALIAS) DmaV::issue(buf + KB, vs, p0, nk, wave, lane);
     };
     // double-buffered form: the cache rows (page lookups) of tile t+2 are fetched while tile t+1's rows fly and tile t is
     // multiplied; K and V rows of a key share the lookup only when their chunk maps agree (D == DV)
-    int tokk[TileDma<D>::N], tokv[V_ALIAS ? 1 : TileDma<DV>::N];
+    int tokk[DmaK::N], tokv[V_ALIAS ? 1 : DmaV::N];
     auto lookup = [&](int t) {
         const int tt = t < ntiles ? t : ntiles - 1;          // past the end: re-read the last tile's ids (never used)
         const int p0 = k_begin + tt * kKeys;
         const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
-        TileDma<D>::lookup(tokk, ks, p0, nk, wave, lane);
-        if constexpr (!V_ALIAS) TileDma<DV>::lookup(tokv, vs, p0, nk, wave, lane);
+        DmaK::lookup(tokk, ks, p0, nk, wave, lane);
+        if constexpr (!V_ALIAS) DmaV::lookup(tokv, vs, p0, nk, wave, lane);
     };
     auto issue_rows = [&](unsigned char* buf) {
-        TileDma<D>::issue_rows(buf, ks, tokk, wave, lane);
-        if constexpr (!V_ALIAS) TileDma<DV>::issue_rows(buf + KB, vs, tokv, wave, lane);
+        DmaK::issue_rows(buf, ks, tokk, wave, lane);
+        if constexpr (!V_ALIAS) DmaV::issue_rows(buf + KB, vs, tokv, wave, lane);
     };
     if (ntiles > 0) {
         if (kDouble) {
@@ -640,16 +649,44 @@ __global__ __launch_bounds__(256, 1) void decode_attention_kernel(const DecodePa
             __syncthreads();
         }
         if (wave_active)
-            core.template tile<V_ALIAS, DV>(cur, V_ALIAS ? cur : cur + KB, k_begin + t * kKeys, limit, scale_log2e, p.logit_cap,
-                                            lane, dsl * DVW);
+            core.template tile<V_ALIAS, DV, 4 / KH>(cur, V_ALIAS ? cur : cur + KB, k_begin + t * kKeys, limit, scale_log2e,
+                                                    p.logit_cap, lane, dsl * DVW, kh * 32);
         if (!kDouble) {
             __syncthreads();                     // the single buffer is free again
             if (t + 1 < ntiles) issue(t + 1, dyn_lds);
         }
     }
     (void)kDma;
-    if (!wave_active) return;
-    const float lsum = core.column_sum(0);
+    // ---- merge the two key halves: the upper half parks {o, m, l} lane for lane in LDS (the tile buffers are dead), the
+    //      lower half rescales both to the common maximum and adds ----
+    float lsum = core.column_sum(0);
+    constexpr int XS = DVW / 4 + 2;                     // floats per lane: its o registers, m, l
+    float* xch = reinterpret_cast<float*>(dyn_lds) + (size_t)(w4 * 64 + lane) * XS;
+    if (KH == 2) __syncthreads();
+    if (KH == 2 && kh == 1 && wave_active) {
+#pragma unroll
+        for (int t = 0; t < DVW / 16; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xch[t * 4 + j] = core.o[0][t][j];
+        xch[DVW / 4] = core.m[0];
+        xch[DVW / 4 + 1] = lsum;
+    }
+    if (KH == 2) __syncthreads();
+    if (kh == 1 || !wave_active) return;
+    if (KH == 2) {
+        const float m1 = xch[DVW / 4], l1 = xch[DVW / 4 + 1];
+        const float m0 = core.m[0];
+        const float mt = fmaxf(m0, m1);
+        // a half that saw no visible key has m = -inf and contributes nothing (and exp2(-inf - -inf) must not be taken)
+        const float a0 = (m0 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m0 - mt);
+        const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - mt);
+#pragma unroll
+        for (int t = 0; t < DVW / 16; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) core.o[0][t][j] = core.o[0][t][j] * a0 + xch[t * 4 + j] * a1;
+        lsum = lsum * a0 + l1 * a1;
+        core.m[0] = mt;
+    }
     if (!col_valid) return;
     float* dst = p.logits + (((int64_t)b * p.HQ + h) * p.splits + split) * (DV + 1);
     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
@@ -822,14 +859,15 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     // V aliases K when it is the same storage with the same strides (MLA: v = k[..., :DV])
     const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
                        a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
-    const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)a->splits), block(256);
+    const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)a->splits);
     const int group = a->HQ / a->HKV;
 #define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
     {                                                                                                              \
         constexpr size_t kb = (size_t)kKeys * DD * 2, vb = (AL) ? 0 : (size_t)kKeys * DDV * 2;                     \
         constexpr size_t lds = (2 * (kb + vb) <= 150 * 1024) ? 2 * (kb + vb) : (kb + vb);                          \
-        hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, AL, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND>), grid, block, lds, s, p);                    \
+        constexpr int kh = DD >= 256 ? 2 : 1;   /* wide heads: the tile's keys are split over two wave groups */         \
+        hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, AL, ND, kh>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND, kh>), grid, dim3(256 * kh), lds, s, p);       \
     }
 #define DEC_CASE(DD, DDV)                                                                                          \
     if (a->D == DD && a->DV == DDV) {                                                                              \
