@@ -481,6 +481,14 @@ __global__ __launch_bounds__(256) void kv_cache_write_kernel(unsigned short* k_b
     for (int c = threadIdx.x; c < DV; c += 256) v_buf[tok * vb_s0 + h * vb_s1 + c] = value[(int64_t)b * v_s0 + h * v_s1 + c];
 }
 
+// A/B knobs of the decode kernel (compile time): images up to this size are double buffered; wave groups for wide heads
+#ifndef SGLK_DEC_DOUBLE_LIMIT
+#define SGLK_DEC_DOUBLE_LIMIT (150 * 1024)
+#endif
+#ifndef SGLK_DEC_KH_WIDE
+#define SGLK_DEC_KH_WIDE 2
+#endif
+
 struct DecodeParams {
     const unsigned short *q, *k_buf, *v_buf;
     int64_t q_s0, q_s1, kb_s0, kb_s1, vb_s0, vb_s1;
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
     typedef TileDma<DV, 256 * KH> DmaV;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     constexpr int KB = kKeys * D * 2, VB = V_ALIAS ? 0 : kKeys * DV * 2;
-    constexpr bool kDouble = 2 * (KB + VB) <= 150 * 1024;
+    constexpr bool kDouble = 2 * (KB + VB) <= SGLK_DEC_DOUBLE_LIMIT;
     constexpr int DVW = DV / NDV;
     constexpr int kDma = DmaK::N + (V_ALIAS ? 0 : DmaV::N);
 
@@ -864,8 +872,8 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
 #define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
     {                                                                                                              \
         constexpr size_t kb = (size_t)kKeys * DD * 2, vb = (AL) ? 0 : (size_t)kKeys * DDV * 2;                     \
-        constexpr size_t lds = (2 * (kb + vb) <= 150 * 1024) ? 2 * (kb + vb) : (kb + vb);                          \
-        constexpr int kh = DD >= 256 ? 2 : 1;   /* wide heads: the tile's keys are split over two wave groups */         \
+        constexpr size_t lds = (2 * (kb + vb) <= SGLK_DEC_DOUBLE_LIMIT) ? 2 * (kb + vb) : (kb + vb);                \
+        constexpr int kh = DD >= 256 ? SGLK_DEC_KH_WIDE : 1;   /* wide heads: the tile's keys are split over two wave groups */ \
         hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, AL, ND, kh>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND, kh>), grid, dim3(256 * kh), lds, s, p);       \
     }
