@@ -58,7 +58,9 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
         }
     }
     if (!need_ic1) {   // plain dense GEMM: fp32 partials of the split-K form (small M)
-        const int ks = generic_ksplit(M, N, K);
+        int ks = generic_ksplit(M, N, K);
+        const int km = mid_dense_ksplit(M, N, K);          // fp8 small-M path (larger of the two plans)
+        if (km > ks) ks = km;
         if (ks > 1) w.partial = take((size_t)ks * M * N * 4);
     }
     w.total = off;
@@ -259,6 +261,38 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         t.out_stride = a->out_stride;
         t.bias = a->bias;
         return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t, t256, s);
+    }
+    // fp8, decode-size M: weight-streaming mid kernel (one "expert"), K cut into ranges until ~2 workgroups per CU exist
+    if (a->wtype == SGLK_W_FP8_E4M3 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->block_k == 128 &&
+        a->block_n > 0 && a->block_n % 16 == 0 && a->x_stride % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 &&
+        ((uintptr_t)a->out % 8) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0) && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        const int ks = mid_dense_ksplit(M, N, K);
+        if (ks >= 1) {
+            const int mt = (int)ceil_div(M, kMidTileM);
+            MoeGemmParams t{};   // no tile table: the kernel derives the row tiles from split_rows
+            fill_tuned(t, a->x, a->x_stride, M, nullptr, a->w, a->w_scale, N, K, a->block_n, nullptr, nullptr);
+            t.n_tiles = N / 128;
+            t.out = (uint16_t*)a->out;
+            t.out_stride = a->out_stride;
+            t.bias = a->bias;
+            t.ksplit = ks;
+            t.split_kblocks = (K >> 7) / ks;
+            t.split_rows = M;
+            t.out_cols = N;
+            t.partial = ks > 1 ? (float*)(ws + w.partial) : nullptr;
+            rc = launch_moe_gemm_fp8w_mid(MODE_PLAIN, t, mt, s);
+            if (rc != SGLK_OK || ks == 1) return rc;
+            GenericGemmParams r{};
+            r.partial = t.partial;
+            r.ksplit = ks;
+            r.split_rows = M;
+            r.n_out = N;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.bias = a->bias;
+            return launch_splitk_reduce(r, s);
+        }
     }
     // bf16 with the reference's packed (VNNI-2) weights on the bf16 matrix cores: large M
     if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && M >= 192 && N % 256 == 0 && K % 32 == 0 && K >= 128 &&

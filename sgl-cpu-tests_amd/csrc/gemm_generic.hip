@@ -383,12 +383,18 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
 #undef GG_LAUNCH
     SGLK_CHECK_LAUNCH("gemm_generic");
     if (split) {
-        const int64_t total = (int64_t)p.split_rows * p.n_out;
-        int64_t rb = ceil_div(total, 256);
-        if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(gg::splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, p.split_rows);
-        SGLK_CHECK_LAUNCH("gemm_generic(split-K reduce)");
+        return launch_splitk_reduce(p, stream);
     }
+    return SGLK_OK;
+}
+
+int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream) {
+    const int64_t total = (int64_t)p.split_rows * p.n_out;
+    if (total == 0) return SGLK_OK;
+    int64_t rb = ceil_div(total, 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(gg::splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, p.split_rows);
+    SGLK_CHECK_LAUNCH("split-K reduce");
     return SGLK_OK;
 }
 

@@ -46,7 +46,8 @@ SGLK_DEV bf16x8 cvt8(unsigned lo, unsigned hi) {
 }
 
 struct TileCtx {
-    int pos0, rows, ntile, kblocks;
+    int pos0, rows, ntile, kblocks;   // kblocks = 128-wide K blocks THIS workgroup walks (the whole reduction, or its range)
+    int kb0, ksr;                     // PLAIN split-K: first block and index of the range
     const unsigned char* wp[2];   // lane's byte inside the first piece of the wave's two weight row-tiles
     const float* sc;              // LDS: this wave's [2][32] block scales
     int row16[2];
@@ -63,7 +64,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     int my_slot = -1;
     float my_tw = 0.f;
     if (MODE == MODE_DOWN && (int)threadIdx.x < c.rows) my_slot = p.sorted_slot[c.pos0 + threadIdx.x];
-    constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
+    constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;   // PLAIN (small-M dense GEMM, one "expert") is shaped like DOWN
     constexpr int PB = 2 * TPW;          // weight pieces per K block per wave
     // the weight stream starts before anything else: K blocks 0 and 1 of the wave's tiles; ring slot = block*PB + tile*2
     // + k half
@@ -88,7 +89,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         int64_t xrow;
         if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[c.pos0 + rr] / p.topk) * p.x_stride;
         else xrow = (int64_t)(c.pos0 + rr) * p.x_stride;
-        xsrc[j] = p.x + xrow + ch * 8;
+        xsrc[j] = p.x + xrow + ch * 8 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
         unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
@@ -187,6 +188,20 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
             v.x = pack_bf16x2(silu_f32(gt[0]) * up[0], silu_f32(gt[1]) * up[1]);
             v.y = pack_bf16x2(silu_f32(gt[2]) * up[2], silu_f32(gt[3]) * up[3]);
             *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + c.ntile * 128 + wave * 16 + q4) = v;
+        } else if (MODE == MODE_PLAIN) {
+            const int col = c.ntile * 128 + wave * 16 + q4;
+            const f32x4 v4 = acc[0][mt];
+            if (p.ksplit > 1) {   // fp32 partial of this K range; bias and the bf16 rounding belong to the ordered reduce
+                float* dst = p.partial + ((int64_t)c.ksr * p.split_rows + c.pos0 + tr) * p.out_cols + col;
+                *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            } else {
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
+                uint2 v;
+                v.x = pack_bf16x2(v4[0] + b4[0], v4[1] + b4[1]);
+                v.y = pack_bf16x2(v4[2] + b4[2], v4[3] + b4[3]);
+                *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + col) = v;
+            }
         } else {
             const int slot = slot_tab[tr];
             const float tw = tw_tab[tr];
@@ -201,36 +216,50 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 1 : 2) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
+__global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int live = p.num_tiles[0] * p.n_tiles;
+    const int nsplit = (MODE == MODE_PLAIN && p.ksplit > 1) ? p.ksplit : 1;
+    // dense (PLAIN without a tile table): the m-tiles are rows [96 i, 96 i + 96) of split_rows rows -- nothing to look up,
+    // which takes two dependent loads off the front of a workgroup that only lives for a few K blocks
+    const bool dense = MODE == MODE_PLAIN && p.tile_info == nullptr;
+    const int mtiles = dense ? (p.split_rows + kTM - 1) / kTM : p.num_tiles[0];
+    const int live = mtiles * p.n_tiles * nsplit;
     if ((int)blockIdx.x >= live) return;
-    const int L = xcd_remap(blockIdx.x, live);
+    const int Ls = xcd_remap(blockIdx.x, live);
+    const int L = Ls / nsplit;
     const int mtile = L / p.n_tiles;
-    const int4 ti = p.tile_info[mtile];
+    int4 ti;
+    if (dense) {
+        const int r0 = mtile * kTM;
+        ti = make_int4(0, r0, p.split_rows - r0 < kTM ? p.split_rows - r0 : kTM, 0);
+    } else {
+        ti = p.tile_info[mtile];
+    }
     const int e = __builtin_amdgcn_readfirstlane(ti.x);
 
     TileCtx c;
     c.ntile = L - mtile * p.n_tiles;
     c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     c.rows = __builtin_amdgcn_readfirstlane(ti.z);
-    c.kblocks = p.C >> 7;
+    c.ksr = Ls - L * nsplit;
+    c.kblocks = nsplit > 1 ? p.split_kblocks : p.C >> 7;
+    c.kb0 = c.ksr * c.kblocks;
     const int ctiles = p.C >> 6;
     if (MODE == MODE_GATE_UP) {          // workgroup = 128 ic1 columns: wave w -> columns ntile*128 + 16w .. +15
         c.row16[0] = c.ntile * 8 + wave;
         c.row16[1] = (p.n_half >> 4) + c.ntile * 8 + wave;
-    } else {                             // workgroup = 128 output columns: wave w -> columns ntile*128 + 16w .. +15
+    } else {                             // DOWN / PLAIN: 128 output columns, wave w -> columns ntile*128 + 16w .. +15
         c.row16[0] = c.ntile * 8 + wave;
         c.row16[1] = c.row16[0];
     }
     const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
-    c.wp[0] = wexp + ((int64_t)c.row16[0] * ctiles) * 1024 + lane * 16;
-    c.wp[1] = wexp + ((int64_t)c.row16[1] * ctiles) * 1024 + lane * 16;
+    c.wp[0] = wexp + ((int64_t)c.row16[0] * ctiles + 2 * c.kb0) * 1024 + lane * 16;
+    c.wp[1] = wexp + ((int64_t)c.row16[1] * ctiles + 2 * c.kb0) * 1024 + lane * 16;
 
     // block scales of the wave's two tiles -> LDS (read back as broadcasts, one per K block)
     float* sc = reinterpret_cast<float*>(lds + kScOff) + wave * 64;
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 1 : 2) void moe_gemm_fp
         const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
         const int a = lane >> 5, kb = lane & 31;
         const int srow = ((a ? c.row16[1] : c.row16[0]) * 16) / p.block_n;
-        sc[lane] = kb < c.kblocks ? scale_e[srow * p.scale_cols + kb] : 0.f;
+        sc[lane] = kb < c.kblocks ? scale_e[srow * p.scale_cols + c.kb0 + kb] : 0.f;
     }
     c.sc = sc;
 
@@ -251,29 +280,48 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 1 : 2) void moe_gemm_fp
 }  // namespace gmid
 
 int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
-    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    const int nsplit = (mode == MODE_PLAIN && p.ksplit > 1) ? p.ksplit : 1;
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles * nsplit;
     if (blocks == 0) return SGLK_OK;
-    if (p.C % 256 != 0 || p.C > 4096) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid: reduction length %d (need %% 256 == 0, <= 4096)", p.C);
+    const int kblocks = nsplit > 1 ? p.split_kblocks : p.C >> 7;
+    if (p.C % 128 != 0 || kblocks < 2 || kblocks % 2 != 0 || kblocks > 32 || (nsplit > 1 && (p.C >> 7) != nsplit * kblocks))
+        SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid: reduction length %d / K range of %d blocks not supported", p.C, kblocks);
+    if (nsplit > 1 && (!p.partial || p.out_cols <= 0)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_mid: split-K without a partial buffer");
     const size_t lds = gmid::kLds;
-    if (mode == MODE_GATE_UP) {
-        static bool attr1 = false;
-        if (!attr1) {
-            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr1 = true;
-        }
-        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
-    } else {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr2 = true;
-        }
-        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
+#define MID_LAUNCH(MD)                                                                                             \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MD>, dim3((unsigned)blocks), dim3(512), lds, stream, p); \
     }
+    if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
+    else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
+    else MID_LAUNCH(MODE_PLAIN)
+#undef MID_LAUNCH
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid");
     return SGLK_OK;
+}
+
+// Small-M fp8 dense GEMMs (decode-size linear layers) on the mid kernel: M <= 192 rows in tiles of up to 96, 128 output
+// columns per workgroup, and the reduction cut into equal ranges of an even number of 128-wide blocks until about 512
+// workgroups exist (two per CU).  Returns 0 when the shape is not taken.
+int mid_dense_ksplit(int M, int N, int K) {
+    if (M <= 0 || M > 192 || N % 128 != 0 || K % 256 != 0) return 0;
+    const int kblocks = K >> 7;
+    const int64_t tiles = (int64_t)ceil_div(M, kMidTileM) * (N / 128);
+    int best = 0;
+    const int per_min = kblocks >= 4 ? 4 : 2;               // a range shorter than 4 blocks is all prologue
+    for (int per = kblocks; per >= per_min; per -= 2) {    // longest ranges first
+        if (kblocks % per != 0 || per > 32) continue;
+        const int ks = kblocks / per;
+        if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
+        best = ks;
+        if (tiles * ks >= 512) break;
+    }
+    return best;
 }
 
 }  // namespace sglk

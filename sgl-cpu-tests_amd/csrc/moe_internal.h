@@ -33,6 +33,10 @@ struct MoeGemmParams {
     const uint16_t* addend;       // PLAIN: bf16 [rows][out columns] added as addend * addend_scale, or null
     int64_t addend_stride;
     float addend_scale;
+    // PLAIN on the mid kernel (small-M dense): split-K -- workgroup = (tile, K range of split_kblocks 128-wide blocks), fp32
+    // partial [range][row][out_cols] reduced by launch_splitk_reduce; ksplit <= 1: whole reduction, bf16 out (+ bias)
+    int ksplit, split_kblocks, split_rows, out_cols;
+    float* partial;
     int* tickets;                 // persistent 256-tile kernel: 8 zeroed counters (one per XCD) or null = static tile split
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
@@ -137,6 +141,11 @@ struct GenericGemmParams {
 int generic_ksplit(int M, int N, int K);
 
 int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream);
+// the ordered reduce of split-K partials alone (fields used: partial, ksplit, split_rows, n_out, out, out_type, out_stride,
+// bias, addend*)
+int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream);
+// split-K plan of a small-M fp8 dense GEMM on the mid kernel: 0 = shape not taken, else the number of K ranges (>= 1)
+int mid_dense_ksplit(int M, int N, int K);
 // m-tile table of a dense problem (one "expert"); identity_slots (optional, [M]) = 0..M-1 for the tuned kernels' row lookup
 int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream);
 // per-row symmetric int8 quantisation: q = rint(x * 127/amax), scale = amax/127, amax = max(|row|, floor)
