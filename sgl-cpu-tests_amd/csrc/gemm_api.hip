@@ -59,8 +59,10 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
     }
     if (!need_ic1) {   // plain dense GEMM: fp32 partials of the split-K form (small M)
         int ks = generic_ksplit(M, N, K);
-        const int km = mid_dense_ksplit(M, N, K);          // fp8 small-M path (larger of the two plans)
+        const int km = mid_dense_ksplit(M, N, K);          // fp8 / bf16 small-M paths (largest of the plans)
         if (km > ks) ks = km;
+        const int kb = bf16_mid_ksplit(M, N, K);
+        if (kb > ks) ks = kb;
         if (ks > 1) w.partial = take((size_t)ks * M * N * 4);
     }
     w.total = off;
@@ -284,6 +286,37 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
             if (rc != SGLK_OK || ks == 1) return rc;
             GenericGemmParams r{};
             r.partial = t.partial;
+            r.ksplit = ks;
+            r.split_rows = M;
+            r.n_out = N;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.bias = a->bias;
+            return launch_splitk_reduce(r, s);
+        }
+    }
+    // bf16 packed weights, decode-size M: the same weight-streaming scheme without a conversion (gemm_bf16_mid.hip)
+    if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->x_stride % 8 == 0 &&
+        ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 && ((uintptr_t)a->out % 8) == 0 &&
+        (!a->bias || ((uintptr_t)a->bias % 16) == 0) && ((uintptr_t)a->w % 4) == 0 && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        const int ks = bf16_mid_ksplit(M, N, K);
+        if (ks >= 1) {
+            BmidParams q{};
+            q.x = (const uint16_t*)a->x;
+            q.x_stride = a->x_stride;
+            q.w = (const uint8_t*)a->w;
+            q.bias = a->bias;
+            q.out = (uint16_t*)a->out;
+            q.out_stride = a->out_stride;
+            q.M = M; q.N = N; q.K = K;
+            q.ksplit = ks;
+            q.split_kblocks = (K >> 7) / ks;
+            q.partial = ks > 1 ? (float*)(ws + w.partial) : nullptr;
+            rc = launch_gemm_bf16_mid(q, s);
+            if (rc != SGLK_OK || ks == 1) return rc;
+            GenericGemmParams r{};
+            r.partial = q.partial;
             r.ksplit = ks;
             r.split_rows = M;
             r.n_out = N;

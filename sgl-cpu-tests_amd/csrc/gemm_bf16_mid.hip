@@ -1,0 +1,198 @@
+// Decode-size dense bf16 GEMM (weight_packed_linear with the reference's VNNI-2 packed weights, M < 192): the
+// weight-streaming scheme of moe_gemm_fp8w_mid.hip without the conversion.
+//
+// out[M][N] = x[M][K] . w[N][K]^T (+ bias), oracle /root/reference/test_gemm.py:15-25.  BASELINE.json config 0 is the
+// (128, 4096, 4096) case.
+//
+// * workgroup = up to 64 (M <= 64) or 128 rows of x  x  128 weight rows  x  one K range; 8 waves, each owns one 16-row weight tile for all
+//   the rows; two workgroups per CU (<= 128 VGPRs) so that one's prologue hides behind the other's stream;
+// * weights never touch LDS.  The packed order [N/32][K/2][32 rows][2 k] keeps, for one k pair, the 32 rows' dwords
+//   together: lane (row r, k group g) gathers the four k pairs of its MFMA A-operand octet with four global_load_dword
+//   (128 B apart), i.e. a 128-wide K block of the wave's tile is 16 dword loads per lane; two blocks are in flight;
+// * x goes global -> LDS by DMA one K block at a time, double buffered (swizzle applied to the source address), one
+//   counted s_waitcnt + one barrier per block -- waits are builtins so that the compiler's own wait-count pass sees them;
+// * the reduction is cut into equal ranges of an even number (>= 4) of K blocks until ~512 workgroups exist; fp32 partials
+//   [range][row][N] are summed in range order by the generic engine's reduce (bias and the bf16 rounding happen there).
+#include "sglk_common.h"
+#include "moe_internal.h"
+
+namespace sglk {
+
+typedef const __attribute__((address_space(1))) void* gptr_bm_t;
+typedef __attribute__((address_space(3))) void* lptr_bm_t;
+
+namespace gbmid {
+
+// Two builds: TM = 64 rows per tile at most (<= 128 VGPRs, two workgroups per CU: one's prologue hides behind the other's
+// stream) for M <= 64, and TM = 128 (one workgroup per CU) for larger M -- with 64-row tiles a 128-row problem streams the
+// weights twice (FETCH_SIZE 73 MB for the 32 MiB matrix of the (128, 4096, 4096) case) and is bound by exactly that.
+
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }   // s_waitcnt vmcnt(n) only (gfx9 encoding)
+
+struct Ctx {
+    int pos0, rows, ntile, kblocks, kb0, ksr;
+    const unsigned char* wp;      // lane's dword of (tile row, k pair 4g) in K block 0 of the range
+};
+
+template <int MT, int TM>
+SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
+    constexpr int kXBuf = TM * 256;
+    // one K block of the wave's tile = 4 k-steps x 4 k pairs; k pair kp of the block sits kp * 128 B further
+    auto load_block = [&](u32x4 (&dst)[4], int kb) __attribute__((always_inline)) {
+        const unsigned char* b = c.wp + (int64_t)kb * (64 * 128);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[s][j] = *reinterpret_cast<const unsigned*>(b + (s * 16 + j) * 128);
+    };
+    u32x4 ring[2][4];
+    load_block(ring[0], 0);
+    load_block(ring[1], 1);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int XV = MT / 2;
+
+    const uint16_t* xsrc[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const int row = (wave * XV + j) * 4 + (lane >> 4), ch = (lane & 15) ^ (row & 15);
+        const int rr = row < c.rows ? row : c.rows - 1;     // padding rows re-read the last row; their outputs are dropped
+        xsrc[j] = p.x + (int64_t)(c.pos0 + rr) * p.x_stride + ch * 8 + (int64_t)c.kb0 * 128;
+    }
+    auto x_dma = [&](int kb) __attribute__((always_inline)) {
+        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+#pragma unroll
+        for (int j = 0; j < XV; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_bm_t)(xsrc[j] + kb * 128), (lptr_bm_t)(dst + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
+        if (prefetch_x) x_dma(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 w[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[s] = __builtin_bit_cast(bf16x8, ring[half][s]);
+        if (refill) load_block(ring[half], kb + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int xr = mt * 16 + r;
+            const unsigned char* base = xb + xr * 256;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (((s * 4 + g) ^ (xr & 15)) << 4));
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[s], x, acc[mt], 0, 0, 0);
+            }
+        }
+        if (prefetch_x) {
+            if (refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));   // all but the 16 refill loads: the DMA has landed
+            else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+
+    x_dma(0);
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __syncthreads();
+    int kb = 0;
+    for (; kb + 2 < c.kblocks; kb += 2) {
+        block(kb, 0, true, true);
+        block(kb + 1, 1, true, true);
+    }
+    block(kb, 0, false, true);
+    block(kb + 1, 1, false, false);
+
+    const int q4 = g * 4;
+    const int col = c.ntile * 128 + wave * 16 + q4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int tr = mt * 16 + r;
+        if (tr >= c.rows) continue;
+        const f32x4 v4 = acc[mt];
+        if (p.ksplit > 1) {
+            float* dst = p.partial + ((int64_t)c.ksr * p.M + c.pos0 + tr) * p.N + col;
+            *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        } else {
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + col); b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w; }
+            uint2 v;
+            v.x = pack_bf16x2(v4[0] + b4[0], v4[1] + b4[1]);
+            v.y = pack_bf16x2(v4[2] + b4[2], v4[3] + b4[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + col) = v;
+        }
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(const BmidParams p) {
+    constexpr int kTM = TM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int n_tiles = p.N >> 7;
+    const int mtiles = (p.M + kTM - 1) / kTM;
+    const int live = mtiles * n_tiles * nsplit;
+    if ((int)blockIdx.x >= live) return;
+    const int Ls = xcd_remap(blockIdx.x, live);
+    const int L = Ls / nsplit;
+    const int mtile = L / n_tiles;
+    Ctx c;
+    c.ntile = L - mtile * n_tiles;
+    c.pos0 = mtile * kTM;
+    c.rows = p.M - c.pos0 < kTM ? p.M - c.pos0 : kTM;
+    c.ksr = Ls - L * nsplit;
+    c.kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
+    c.kb0 = c.ksr * c.kblocks;
+    // weight row of this lane: tile row (lane & 15) of the wave's 16-row tile; k group g = lane >> 4 -> k pairs 4g .. 4g+3
+    const int R = c.ntile * 128 + wave * 16 + (lane & 15);
+    const int64_t dword = ((int64_t)(R >> 5) * (p.K >> 1) + (int64_t)c.kb0 * 64 + (lane >> 4) * 4) * 32 + (R & 31);
+    c.wp = p.w + dword * 4;
+    const int mt = (c.rows + 15) >> 4;
+    if (mt <= 2) run<2, TM>(p, lds, c);
+    else if (TM == 64 || mt <= 4) run<4, TM>(p, lds, c);
+    else if (mt <= 6) run<(TM == 64 ? 4 : 6), TM>(p, lds, c);
+    else run<(TM == 64 ? 4 : 8), TM>(p, lds, c);
+}
+
+}  // namespace gbmid
+
+// 0 = shape not taken, else the number of K ranges (>= 1); same policy as mid_dense_ksplit
+int bf16_mid_ksplit(int M, int N, int K) {
+    if (M <= 0 || M >= 192 || N % 128 != 0 || K % 256 != 0) return 0;
+    const int kblocks = K >> 7;
+    const int64_t tiles = (int64_t)ceil_div(M, M <= 64 ? 64 : 128) * (N / 128);
+    const int per_min = kblocks >= 4 ? 4 : 2;
+    int best = 0;
+    for (int per = kblocks; per >= per_min; per -= 2) {
+        if (kblocks % per != 0) continue;
+        const int ks = kblocks / per;
+        if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
+        best = ks;
+        if (tiles * ks >= 512) break;
+    }
+    return best;
+}
+
+int launch_gemm_bf16_mid(const BmidParams& p, hipStream_t stream) {
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
+    if (p.K % 128 != 0 || p.N % 128 != 0 || kblocks < 2 || kblocks % 2 != 0 || (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial)))
+        SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_mid: N=%d K=%d with %d ranges not supported", p.N, p.K, nsplit);
+    const int tm = p.M <= 64 ? 64 : 128;
+    const int64_t blocks = (int64_t)ceil_div(p.M, tm) * (p.N >> 7) * nsplit;
+    if (blocks == 0) return SGLK_OK;
+    if (tm == 64) hipLaunchKernelGGL(gbmid::gemm_bf16_mid_kernel<64>, dim3((unsigned)blocks), dim3(512), 2 * 64 * 256, stream, p);
+    else hipLaunchKernelGGL(gbmid::gemm_bf16_mid_kernel<128>, dim3((unsigned)blocks), dim3(512), 2 * 128 * 256, stream, p);
+    SGLK_CHECK_LAUNCH("gemm_bf16_mid");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

@@ -137,6 +137,21 @@ struct GenericGemmParams {
     float* partial;
 };
 
+// decode-size dense bf16 GEMM on packed (VNNI-2) weights, weight-streaming (gemm_bf16_mid.hip)
+struct BmidParams {
+    const uint16_t* x;        // bf16 [M][K], row stride x_stride elements (multiple of 8), 16-byte aligned
+    int64_t x_stride;
+    const uint8_t* w;         // packed bf16 [N/32][K/2][32][2]
+    const float* bias;        // [N] f32 or null (ksplit <= 1 only; with split-K the reduce adds it)
+    uint16_t* out;            // bf16 [M][N]
+    int64_t out_stride;
+    int M, N, K;
+    int ksplit, split_kblocks;   // K ranges of split_kblocks 128-wide blocks; <= 1: whole reduction
+    float* partial;           // [ksplit][M][N] fp32
+};
+int bf16_mid_ksplit(int M, int N, int K);   // 0 = shape not taken, else the number of K ranges
+int launch_gemm_bf16_mid(const BmidParams& p, hipStream_t stream);
+
 // split-K plan of a small-M dense GEMM (same answer for the workspace size and for the launch): 1 = no split
 int generic_ksplit(int M, int N, int K);
 
