@@ -93,7 +93,18 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // Workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous tile range [xs, xs + xl) (equal
     // shares, bijective for any count) so that one expert's weights and one m-tile's activations stay in one L2, and
     // the workgroups of an XCD take consecutive tiles of that range in every round.
-    const int live = p.num_tiles[0] * p.n_tiles;
+    const int nmt = p.num_tiles[0];
+    const int live = nmt * p.n_tiles;
+    // linear tile id -> (m-tile, column tile).  Default: column tiles fastest (the six workgroups of an m-tile are
+    // neighbours and share its gathered token rows).  SGLK_TILE_ORDER_N_MAJOR (A/B build): m-tiles fastest, so the m-tiles of
+    // one expert that stream the same weight slab are neighbours instead.
+#ifdef SGLK_TILE_ORDER_N_MAJOR
+#define SGLK_SPLIT_L(Lx, mt_, nt_) const int nt_ = (Lx) / nmt, mt_ = (Lx) - nt_ * nmt
+#define SGLK_MT_OF(Lx) ((Lx) % nmt)
+#else
+#define SGLK_SPLIT_L(Lx, mt_, nt_) const int mt_ = (Lx) / p.n_tiles, nt_ = (Lx) - mt_ * p.n_tiles
+#define SGLK_MT_OF(Lx) ((Lx) / p.n_tiles)
+#endif
     int xs, xl, nbx;
     {
         const int x = blockIdx.x & 7, q = live >> 3, r = live & 7;
@@ -124,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     };
     const int kblocks_ = p.C >> 7;
     auto fetch_meta = [&](int Lq, Meta& m) {
-        const int mt = Lq / p.n_tiles, nt = Lq - mt * p.n_tiles;
+        SGLK_SPLIT_L(Lq, mt, nt);
+        (void)mt;
         const int e_ = __builtin_amdgcn_readfirstlane(m.ti.x), pos0_ = __builtin_amdgcn_readfirstlane(m.ti.y);
         const int rows_ = __builtin_amdgcn_readfirstlane(m.ti.z);
         const float* scale_e = p.w_scale + (int64_t)e_ * p.scale_rows * p.scale_cols;
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         }
     };
     Meta cur, nxt;
-    cur.ti = p.tile_info[(xs + jt) / p.n_tiles];
+    cur.ti = p.tile_info[SGLK_MT_OF(xs + jt)];
     fetch_meta(xs + jt, cur);
     if (MODE == MODE_DOWN && cur.my_slot >= 0) cur.tw = p.topk_weights[cur.my_slot];
     nxt = cur;
@@ -172,13 +184,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // VGPR across the main loop and is consumed after it
     if (has_next_tile) {
         const __attribute__((address_space(4))) int* tp = reinterpret_cast<const __attribute__((address_space(4))) int*>(
-            reinterpret_cast<uintptr_t>(p.tile_info + (xs + jt_n) / p.n_tiles));
+            reinterpret_cast<uintptr_t>(p.tile_info + SGLK_MT_OF(xs + jt_n)));
         nxt.ti.x = tp[0];
         nxt.ti.y = tp[1];
         nxt.ti.z = tp[2];
     }
-    const int mtile = L / p.n_tiles;
-    const int ntile = L - mtile * p.n_tiles;
+    SGLK_SPLIT_L(L, mtile, ntile);
+    (void)mtile;
     const int e = __builtin_amdgcn_readfirstlane(cur.ti.x);
     const int pos0 = __builtin_amdgcn_readfirstlane(cur.ti.y);
     const int rows = __builtin_amdgcn_readfirstlane(cur.ti.z);
