@@ -17,7 +17,7 @@ struct StageTimer {
 };
 
 struct Workspace {
-    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tickets, ic1, ic2, xq, xs, ic1q, ic1s, total;
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tile_info_b, num_tiles_b, tickets, ic1, ic2, xq, xs, ic1q, ic1s, total;
 };
 
 // Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E).  Measured crossovers at Qwen3
@@ -70,6 +70,8 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     w.expert_off = take((size_t)(E + 1) * sizeof(int));
     w.tile_info = take((size_t)max_tiles * 4 * sizeof(int));
     w.num_tiles = take(sizeof(int));
+    w.tile_info_b = take((size_t)E * 4 * sizeof(int));   // tail tiles (at most one per expert) of the 256-row plan
+    w.num_tiles_b = take(sizeof(int));
     w.tickets = take(16 * sizeof(int));
     w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
@@ -81,6 +83,31 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     }
     w.total = off;
     return w;
+}
+
+// Side stream of the tail-tile launches (per thread and device, created on first use, never destroyed): the tail tiles'
+// GEMM-1 -> GEMM-2 chain is independent of the full tiles' (it reads and writes its own rows of ic1 / ic2), so it runs beside
+// the two big launches and fills the CUs their last tiles leave idle; fork after moe_align, join before the combine.
+struct SideStream {
+    hipStream_t st = nullptr;
+    hipEvent_t ev[16] = {};
+    unsigned next = 0;
+    int state = 0;   // 0 = not tried, 1 = ready, -1 = unavailable
+};
+static SideStream* side_stream() {
+    static thread_local SideStream ctx[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream& c = ctx[dev];
+    if (c.state == 0) {
+        c.state = -1;
+        if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) == hipSuccess) {
+            bool ok = true;
+            for (auto& e : c.ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (ok) c.state = 1;
+        }
+    }
+    return c.state == 1 ? &c : nullptr;
 }
 
 // shapes / layouts the tuned fp8 kernels (moe_gemm_fp8w*.hip) accept; everything else runs on the generic engine
@@ -174,9 +201,22 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     const bool tuned_i8 = tuned_int8_ok(a);
     const bool tuned_b16 = tuned_bf16_ok(a);
     const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM);
+    // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
+    // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
+    // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
+    static const char* tail_env = getenv("SGLK_TAIL_SPLIT");   // 0 = off, 1 = on the caller's stream, default = side stream
+    // Same-box A/B at Qwen3 dims (tools/ab_tail_split.sh): M = 3929 -1.8 %, 4096 -8 %, 8192 -0.7 %, but 16384 +1.5 % and
+    // 32768 +1.7 % (few tails per full tile, and the side launches get in the big kernels' way) -> only below ~640 rows per
+    // expert.
+    const bool split_tails = tuned && tile_m == 256 && K % 256 == 0 && N % 256 == 0 && K <= 4096 && N <= 4096 &&
+                             (int64_t)M * topk < (int64_t)640 * E && !(tail_env && tail_env[0] == '0');
+    SideStream* side = (split_tails && !(tail_env && tail_env[0] == '1')) ? side_stream() : nullptr;
+    int* tile_info_b = (int*)(ws + w.tile_info_b);
+    int* num_tiles_b = (int*)(ws + w.num_tiles_b);
     mark(0);
-    int rc = sglk_moe_align(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
-                            ws + w.align_ws, w.sorted_slot - w.align_ws, stream);
+    int rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
+                                    split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
+                                    w.sorted_slot - w.align_ws, stream);
     if (rc != SGLK_OK) return rc;
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
@@ -213,6 +253,48 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         // 256-token tiles: 32x32x16 MFMA kernel unless the scale blocks are finer than its 32-row operand tiles
         static const bool force16 = getenv("SGLK_MFMA16") != nullptr;
         const bool use32 = !force16 && a->block_n % 32 == 0;
+        hipEvent_t ev_join = nullptr;
+        if (split_tails) {
+            const int tails_max = E < max_tiles ? E : max_tiles;
+            MoeGemmParams t1 = g1;
+            t1.tile_info = (const int4*)tile_info_b;
+            t1.num_tiles = num_tiles_b;
+            t1.tickets = nullptr;
+            MoeGemmParams t2{};
+            t2.x = ic1;
+            t2.x_stride = N;
+            t2.x_bytes = (int64_t)M * topk * N * 2;
+            t2.sorted_slot = sorted_slot;
+            t2.topk = topk;
+            t2.w = (const uint8_t*)a->w2;
+            t2.w_expert_stride = (int64_t)K * N;
+            t2.w_scale = a->w2_scale;
+            t2.scale_rows = (int)ceil_div(K, a->block_n);
+            t2.scale_cols = N / 128;
+            t2.block_n = a->block_n;
+            t2.C = N;
+            t2.tile_info = (const int4*)tile_info_b;
+            t2.num_tiles = num_tiles_b;
+            t2.n_tiles = K / 128;
+            t2.out = ic2;
+            t2.out_stride = K;
+            t2.topk_weights = a->topk_weights;
+            hipStream_t ts = s;
+            if (side) {   // fork: the side stream starts once moe_align (and the ticket reset) are done
+                hipEvent_t ev_fork = side->ev[side->next++ & 15];
+                ev_join = side->ev[side->next++ & 15];
+                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side->st, ev_fork, 0) != hipSuccess)
+                    SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream fork failed");
+                ts = side->st;
+            }
+            // with a side stream both tail launches go out here, before the big GEMM-1, and overlap it and GEMM-2; on the
+            // caller's stream they simply run first
+            rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, t1, tails_max, ts);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
+            if (rc != SGLK_OK) return rc;
+            if (side && hipEventRecord(ev_join, side->st) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream record failed");
+        }
         rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_GATE_UP, g1, max_tiles, s)
                                     : launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s))
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_GATE_UP, g1, max_tiles, s)
@@ -251,6 +333,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
              : tile_m == kMidTileM    ? launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s)
                                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
+        // join: the combine needs the tail tiles' rows of ic2 too
+        if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream join failed");
         mark(3);
     } else if (tuned_i8) {
         // W8A8 on the int8 matrix cores: quantise x per token, GEMM-1 (+SiLU*mul, fp32 out), quantise ic1 per row,

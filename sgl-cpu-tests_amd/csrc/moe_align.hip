@@ -39,12 +39,16 @@ __global__ __launch_bounds__(64) void moe_count_kernel(const int* __restrict__ i
     for (int e = lane; e < E; e += 64) counts[(size_t)blockIdx.x * E + e] = hist[e];
 }
 
+// tail_max > 0: the last of an expert's SEVERAL tiles goes to a second table (tile_info_b / num_tiles_b) when it has at most tail_max rows
+// -- fused_experts runs those tail tiles on the weight-streaming mid kernel instead of paying a full 256-row tile for them.
 __global__ __launch_bounds__(1024) void moe_scan_kernel(int* __restrict__ counts, int nchunk, int E, int tile_m,
                                                         int max_tiles, int* __restrict__ expert_off,
-                                                        int* __restrict__ tile_info, int* __restrict__ num_tiles) {
+                                                        int* __restrict__ tile_info, int* __restrict__ num_tiles,
+                                                        int tail_max, int* __restrict__ tile_info_b,
+                                                        int* __restrict__ num_tiles_b) {
     __shared__ int part_sum[kMaxExperts];   // [part][expert], parts * E <= 1024
     __shared__ int cnt[kMaxExperts];
-    __shared__ int2 scan[2][kMaxExperts];   // {slots, tiles} inclusive scans, ping-pong
+    __shared__ int4 scan[2][kMaxExperts];   // {slots, tiles, tail tiles} inclusive scans, ping-pong
     const int tid = threadIdx.x;
     // `parts` threads share one expert's column of the [chunk][expert] table, each walking a contiguous chunk range
     const int parts = kMaxExperts / E;
@@ -79,34 +83,40 @@ __global__ __launch_bounds__(1024) void moe_scan_kernel(int* __restrict__ counts
     if (part == 0) cnt[e_of] = total;
     __syncthreads();
     total = (e < E) ? cnt[e] : 0;
-    scan[0][e] = make_int2(total, (total + tile_m - 1) / tile_m);
+    const int nt_all = (total + tile_m - 1) / tile_m;
+    const int rem = total - (nt_all - 1) * tile_m;             // rows of the expert's last tile (nt_all > 0)
+    const int tail = (tail_max > 0 && nt_all >= 2 && rem <= tail_max) ? 1 : 0;   // a true tail: the expert has full tiles too
+    scan[0][e] = make_int4(total, nt_all - tail, tail, 0);
     __syncthreads();
     int cur = 0;
     for (int d = 1; d < kMaxExperts; d <<= 1) {
-        int2 v = scan[cur][e];
+        int4 v = scan[cur][e];
         if (e >= d) {
-            const int2 o = scan[cur][e - d];
+            const int4 o = scan[cur][e - d];
             v.x += o.x;
             v.y += o.y;
+            v.z += o.z;
         }
         scan[cur ^ 1][e] = v;
         cur ^= 1;
         __syncthreads();
     }
-    const int2 incl = scan[cur][e];
+    const int4 incl = scan[cur][e];
     if (e < E) {
         const int off = incl.x - total;
         expert_off[e] = off;
         if (e == E - 1) {
             expert_off[E] = incl.x;
             num_tiles[0] = incl.y < max_tiles ? incl.y : max_tiles;
+            if (num_tiles_b) num_tiles_b[0] = incl.z;
         }
-        const int nt = (total + tile_m - 1) / tile_m;
+        const int nt = nt_all - tail;
         int t0 = incl.y - nt;
         for (int i = 0; i < nt && t0 + i < max_tiles; ++i) {
             const int rows = total - i * tile_m < tile_m ? total - i * tile_m : tile_m;
             reinterpret_cast<int4*>(tile_info)[t0 + i] = make_int4(e, off + i * tile_m, rows, 0);
         }
+        if (tail) reinterpret_cast<int4*>(tile_info_b)[incl.z - 1] = make_int4(e, off + (nt_all - 1) * tile_m, rem, 0);
     }
 }
 
@@ -258,9 +268,11 @@ extern "C" int32_t sglk_moe_max_tiles(int32_t M, int32_t E, int32_t topk, int32_
     return (int32_t)(S / tile_m + partial);
 }
 
-extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
-                              int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+namespace sglk {
+int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
+                           int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
+                           int32_t tail_max, int32_t* tile_info_b, int32_t* num_tiles_b,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     SGLK_REQUIRE(M >= 0 && E > 0 && topk > 0 && tile_m > 0, SGLK_ERR_INVALID, "moe_align: bad sizes M=%d E=%d topk=%d", M, E, topk);
     SGLK_REQUIRE(E <= kMaxExperts, SGLK_ERR_SHAPE, "moe_align: at most %d experts supported (got %d)", kMaxExperts, E);
     SGLK_REQUIRE((int64_t)M * topk < (1ll << 31), SGLK_ERR_SHAPE, "moe_align: M*topk overflows int32");
@@ -268,6 +280,7 @@ extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int
     SGLK_REQUIRE(M == 0 || (topk_ids && sorted_slot), SGLK_ERR_INVALID, "moe_align: null pointer");
     SGLK_REQUIRE(workspace_bytes >= sglk_moe_align_workspace_bytes(M, E, topk), SGLK_ERR_WORKSPACE,
                  "moe_align: workspace too small");
+    SGLK_REQUIRE(tail_max <= 0 || (tile_info_b && num_tiles_b), SGLK_ERR_INVALID, "moe_align: tail table missing");
     hipStream_t s = (hipStream_t)stream;
     const int S = M * topk;
     const int nchunk = (int)ceil_div(S, kAlignChunk);
@@ -275,7 +288,7 @@ extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int
     int nbits = 0;
     while ((1 << nbits) < E) ++nbits;
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
-    if (S <= kSmallSlots && E <= kSmallMaxE && getenv("SGLK_ALIGN_3PASS") == nullptr) {
+    if (tail_max <= 0 && S <= kSmallSlots && E <= kSmallMaxE && getenv("SGLK_ALIGN_3PASS") == nullptr) {
         hipLaunchKernelGGL(moe_align_small_kernel, dim3(1), dim3(1024), 0, s, topk_ids, S, E, nbits, tile_m, max_tiles,
                            sorted_slot, expert_off, tile_info, num_tiles);
         SGLK_CHECK_LAUNCH("moe_align");
@@ -285,11 +298,19 @@ extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int
         hipLaunchKernelGGL(moe_count_kernel, dim3(nchunk), dim3(64), 0, s, topk_ids, S, E, counts);
     }
     hipLaunchKernelGGL(moe_scan_kernel, dim3(1), dim3(kMaxExperts), 0, s, counts, nchunk, E, tile_m, max_tiles,
-                       expert_off, tile_info, num_tiles);
+                       expert_off, tile_info, num_tiles, tail_max > 0 ? tail_max : 0, tile_info_b, num_tiles_b);
     if (nchunk > 0) {
         hipLaunchKernelGGL(moe_scatter_kernel, dim3(nchunk), dim3(64), 0, s, topk_ids, S, E, nbits, counts,
                            expert_off, sorted_slot);
     }
     SGLK_CHECK_LAUNCH("moe_align");
     return SGLK_OK;
+}
+}  // namespace sglk
+
+extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
+                              int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    return sglk::launch_moe_align_split(topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles, 0, nullptr,
+                                        nullptr, workspace, workspace_bytes, stream);
 }

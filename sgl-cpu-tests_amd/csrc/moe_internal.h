@@ -177,6 +177,12 @@ int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles
 // (moe_gemm_fp8w_mid.hip); tile table built with tile_m = 128
 int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
+// moe_align with a second tile table: an expert's last tile lands in tile_info_b when it has at most tail_max rows
+// (tail_max <= 0: exactly sglk_moe_align)
+int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,
+                           int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, int32_t tail_max,
+                           int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream);
+
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,
                        int K, int E, int topk, hipStream_t stream);
