@@ -204,7 +204,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
-    static const char* tail_env = getenv("SGLK_TAIL_SPLIT");   // 0 = off, 1 = on the caller's stream, default = side stream
+    const char* tail_env = getenv("SGLK_TAIL_SPLIT");   // 0 = off, 1 = on the caller's stream, default = side stream
     // Same-box A/B at Qwen3 dims (tools/ab_tail_split.sh): M = 3929 -1.8 %, 4096 -8 %, 8192 -0.7 %, but 16384 +1.5 % and
     // 32768 +1.7 % (few tails per full tile, and the side launches get in the big kernels' way) -> only below ~640 rows per
     // expert.

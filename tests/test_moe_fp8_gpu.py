@@ -169,3 +169,38 @@ def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
     inp["topk_weight"] = inp["topk_weight"] * k
     out, _ = run_fp8(ops, inp, block)
     check_close(out, ref * k, f"tile_m={tile_m} block={block}")
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_fused_experts_fp8_tail_tiles(ops, mode, monkeypatch):
+    """Experts with one full 256-row tile plus a short tail (rows ~ 300): the tails run on the mid kernel -- off, on the
+    caller's stream, or on the library's side stream (same bits as on the caller's); also under hipGraph capture."""
+    monkeypatch.setenv("SGLK_TAIL_SPLIT", mode)
+    M, N, K, E, topk, block = 600, 256, 512, 8, 4, (128, 128)
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, block[0], block[1], False, 9055)
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
+                                     inp["topk_weight"], inp["topk_ids"])
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    out, d = run_fp8(ops, inp, block)
+    check_close(out, ref * k, f"tail split mode {mode}")
+    # the stream the tails run on must not change the bits (the kernel they run on may: its rounding points differ)
+    if mode == "1":
+        test_fused_experts_fp8_tail_tiles._bits = out.cpu()
+    elif mode == "2" and hasattr(test_fused_experts_fp8_tail_tiles, "_bits"):
+        assert torch.equal(test_fused_experts_fp8_tail_tiles._bits, out.cpu())
+    # capture + replay (the side stream is forked and joined inside the captured call)
+    w1p, w2p = ops.convert_weight_packed(d["w1"]), ops.convert_weight_packed(d["w2"])
+    call = lambda: ops.fused_experts_cpu(d["a"], w1p, w2p, d["topk_weight"], d["topk_ids"], False, False, True, d["w1s"],
+                                         d["w2s"], list(block), None, None, True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = call()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g.cpu(), out.cpu())
