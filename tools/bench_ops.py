@@ -121,6 +121,34 @@ def bench_moe_literal():
                  tflops=round(M * topk * 6 * N * K / ms / 1e9, 2), tokens_per_s=round(M / ms * 1e3))
 
 
+def bench_moe_offload():
+    """The reference's expert-offloading bench (bench_moe_offloading_cpu.py:15-175): 8 resident experts of 128, ids of the
+    non-resident ones padded with -1 at ratio topk / num_experts, all-masked rows dropped, M = 64, N = 256, K = 4096,
+    prepacked weights, inplace=True.  Also a batch 64 x larger, where the masked slots are the bulk of the id matrix."""
+    N, K, E, topk, total_experts = 256, 4096, 8, 8, 128
+    g = torch.Generator(device="cuda").manual_seed(7)
+    wb1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
+    wb2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 0.02).bfloat16())
+    wf1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    wf2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    s1 = torch.rand(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-4
+    s2 = torch.rand(E, K // 128, N // 128, device="cuda", generator=g) * 1e-4
+    for M in (64, 4096):
+        ids = torch.randint(0, E, (M, topk), device="cuda", generator=g, dtype=torch.int32)
+        keep = torch.rand(M, topk, device="cuda", generator=g) < topk / total_experts
+        ids[~keep] = -1
+        ids = ids[(ids >= 0).any(dim=1)]
+        m_act = ids.shape[0]
+        tw = torch.rand(m_act, topk, device="cuda", generator=g)
+        a = (torch.randn(m_act, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        valid = int((ids >= 0).sum())
+        for kind, fn in (("bf16", lambda i: ops.fused_experts_cpu(a, wb1, wb2, tw, ids, True, False, False, None, None, None, None, None, True)),
+                         ("fp8", lambda i: ops.fused_experts_cpu(a, wf1, wf2, tw, ids, True, False, True, s1, s2, [128, 128], None, None, True))):
+            ms = timed(fn, 30)
+            emit(op="fused_experts_offloading_shape", weights=kind, M=M, rows_after_masking=m_act, valid_slots=valid, N=N, K=K, E=E,
+                 topk=topk, ms=round(ms, 4), tflops=round(valid * 6 * N * K / ms / 1e9, 3))
+
+
 def bench_moe_int8():
     """int8 W8A8 fused_experts (bench_moe.py:89-106) at the Qwen3-30B-A3B expert shape, prepacked weights."""
     K, N, E, topk = 2048, 768, 128, 8
@@ -303,7 +331,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_offload": bench_moe_offload, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
