@@ -37,8 +37,8 @@ int pick_tile_m(int M, int N, int K, int E, int topk) {
     // stream kernel: both reduction lengths (K for GEMM-1, N for GEMM-2) must be multiples of 256 (ring of 8 pieces)
     const bool ok_stream = (K % 256 == 0) && (N % 256 == 0) && (int64_t)kStreamTileM * K * 2 <= 150 * 1024 &&
                            (int64_t)kStreamTileM * N * 2 <= 150 * 1024;
-    // mid kernel: reduction lengths in whole 256s up to 4096 (scale table), 128 ic1 / 256 output columns per workgroup
-    const bool ok_mid = (K % 256 == 0) && (N % 256 == 0) && K <= 4096 && N <= 4096;
+    // mid kernel: reduction lengths in whole 128s, 2 .. 64 blocks (scale table), 128 ic1 / 128 output columns per workgroup
+    const bool ok_mid = (K % 128 == 0) && (N % 128 == 0) && K >= 256 && N >= 256 && K <= 8192 && N <= 8192;
     if (force) {
         const int f = atoi(force);
         if (f == 256 && ok256) return 256;

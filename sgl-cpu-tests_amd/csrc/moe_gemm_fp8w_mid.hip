@@ -30,8 +30,9 @@ namespace gmid {
 
 constexpr int kTM = kMidTileM;        // 128 tokens
 constexpr int kXBuf = kTM * 256;      // one K block of the token tile: 32 KiB
-constexpr int kScOff = 2 * kXBuf;     // then the scale table [8 waves][2 tiles][32 K blocks] f32
-constexpr int kRowTabOff = kScOff + 8 * 2 * 32 * 4;   // DOWN: output slot and routing weight of every tile row
+constexpr int kMaxKB = 64;             // K blocks a workgroup may walk (reduction length or split-K range <= 8192)
+constexpr int kScOff = 2 * kXBuf;     // then the scale table [8 waves][2 tiles][kMaxKB] f32
+constexpr int kRowTabOff = kScOff + 8 * 2 * kMaxKB * 4;   // DOWN: output slot and routing weight of every tile row
 constexpr int kLds = kRowTabOff + 2 * kTM * 4;
 
 SGLK_DEV bf16x8 cvt8(unsigned lo, unsigned hi) {
@@ -57,7 +58,7 @@ struct TileCtx {
 // up), 1 for DOWN -- half the registers, so that two workgroups share a CU and one's prologue (tile table -> rows ->
 // first activations, three dependent round trips) and epilogue hide behind the other's stream; DOWN's reduction is
 // short (N = 768: six K blocks), so without that overlap the prologue is a third of its time.
-template <int MODE, int MT>
+template <int MODE, int MT, bool ODD>
 SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
     // DOWN: the rows' output slots and routing weights are two dependent round trips; they start here and wait in LDS
     // for the epilogue instead of being fetched by it
@@ -128,7 +129,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         __builtin_amdgcn_sched_barrier(0);
         float sc[TPW];
 #pragma unroll
-        for (int a = 0; a < TPW; ++a) sc[a] = c.sc[a * 32 + kb];
+        for (int a = 0; a < TPW; ++a) sc[a] = c.sc[a * kMaxKB + kb];
         const unsigned char* xb = lds + (kb & 1) * kXBuf;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -166,15 +167,26 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         tw_tab[tid] = my_tw;
     }
     __syncthreads();
-    // kblocks is even and >= 2 (C % 256 == 0).  The steady state has no branch between a load and its use (with one the
-    // compiler falls back to s_waitcnt vmcnt(0) per piece and the ring degenerates)
+    // kblocks >= 2.  The steady state has no branch between a load and its use (with one the compiler falls back to
+    // s_waitcnt vmcnt(0) per piece and the ring degenerates): pairs of blocks with unconditional refills, then a tail of two
+    // (even count) or three (odd count, e.g. N = 384 -> 3 blocks) blocks whose flags are literals too
     int kb = 0;
-    for (; kb + 2 < c.kblocks; kb += 2) {
+    if (!ODD) {   // the parity of the block count is a template parameter: both tails in one kernel cost registers
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
+        block(kb, 0, false, true);
+        block(kb + 1, 1, false, false);
+    } else {
+        for (; kb + 3 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
         block(kb, 0, true, true);
-        block(kb + 1, 1, true, true);
+        block(kb + 1, 1, false, true);
+        block(kb + 2, 0, false, false);
     }
-    block(kb, 0, false, true);
-    block(kb + 1, 1, false, false);
 
     // ---- epilogue: lane holds weight rows 4g..4g+3 of each tile for token r of every column tile ----------------------
     const int q4 = g * 4;
@@ -215,7 +227,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     }
 }
 
-template <int MODE>
+template <int MODE, bool ODD>
 __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -262,19 +274,21 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp
     c.wp[1] = wexp + ((int64_t)c.row16[1] * ctiles + 2 * c.kb0) * 1024 + lane * 16;
 
     // block scales of the wave's two tiles -> LDS (read back as broadcasts, one per K block)
-    float* sc = reinterpret_cast<float*>(lds + kScOff) + wave * 64;
+    float* sc = reinterpret_cast<float*>(lds + kScOff) + wave * (2 * kMaxKB);
     {
         const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
-        const int a = lane >> 5, kb = lane & 31;
-        const int srow = ((a ? c.row16[1] : c.row16[0]) * 16) / p.block_n;
-        sc[lane] = kb < c.kblocks ? scale_e[srow * p.scale_cols + c.kb0 + kb] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {       // lane = K block of the workgroup's range
+            const int srow = ((a ? c.row16[1] : c.row16[0]) * 16) / p.block_n;
+            sc[a * kMaxKB + lane] = lane < c.kblocks ? scale_e[srow * p.scale_cols + c.kb0 + lane] : 0.f;
+        }
     }
     c.sc = sc;
 
     const int mt = (c.rows + 15) >> 4;
-    if (mt <= 2) run<MODE, 2>(p, lds, c);
-    else if (mt <= 4) run<MODE, 4>(p, lds, c);
-    else run<MODE, 6>(p, lds, c);
+    if (mt <= 2) run<MODE, 2, ODD>(p, lds, c);
+    else if (mt <= 4) run<MODE, 4, ODD>(p, lds, c);
+    else run<MODE, 6, ODD>(p, lds, c);
 }
 
 }  // namespace gmid
@@ -284,23 +298,28 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles * nsplit;
     if (blocks == 0) return SGLK_OK;
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.C >> 7;
-    if (p.C % 128 != 0 || kblocks < 2 || kblocks % 2 != 0 || kblocks > 32 || (nsplit > 1 && (p.C >> 7) != nsplit * kblocks))
+    if (p.C % 128 != 0 || kblocks < 2 || kblocks > gmid::kMaxKB || (nsplit > 1 && (p.C >> 7) != nsplit * kblocks))
         SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid: reduction length %d / K range of %d blocks not supported", p.C, kblocks);
     if (nsplit > 1 && (!p.partial || p.out_cols <= 0)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_mid: split-K without a partial buffer");
     const size_t lds = gmid::kLds;
-#define MID_LAUNCH(MD)                                                                                             \
+#define MID_LAUNCH2(MD, OD)                                                                                        \
     {                                                                                                              \
         static bool attr = false;                                                                                  \
         if (!attr) {                                                                                               \
-            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MD, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_kernel<MD>, dim3((unsigned)blocks), dim3(512), lds, stream, p); \
+        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
+    }
+#define MID_LAUNCH(MD)                                                                                             \
+    {                                                                                                              \
+        if (kblocks & 1) MID_LAUNCH2(MD, true) else MID_LAUNCH2(MD, false)                                         \
     }
     if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
     else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
     else MID_LAUNCH(MODE_PLAIN)
 #undef MID_LAUNCH
+#undef MID_LAUNCH2
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid");
     return SGLK_OK;
 }

@@ -204,3 +204,21 @@ def test_fused_experts_fp8_tail_tiles(ops, mode, monkeypatch):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out_g.cpu(), out.cpu())
+
+
+@pytest.mark.parametrize("shape", [(200, 384, 640, 8, 2), (64, 256, 4352, 4, 2), (300, 384, 7168, 8, 4)],
+                         ids=lambda s: "M%d_N%d_K%d_E%d_top%d" % s)
+def test_fused_experts_fp8_mid_odd_and_long_reductions(ops, shape, monkeypatch):
+    """The weight-streaming mid kernel beyond the Qwen3 shape: odd numbers of 128-wide K blocks (N = 384 -> 3, K = 640 -> 5)
+    and more than 32 of them (K = 4352 -> 34, K = 7168 -> 56: the reference bench's literal expert shape), against the
+    plain-C oracle."""
+    monkeypatch.setenv("SGLK_MOE_TILE_M", "96")
+    M, N, K, E, topk = shape
+    block = (128, 128)
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, block[0], block[1], False, 9077 + M)
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
+                                     inp["topk_weight"], inp["topk_ids"])
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    out, _ = run_fp8(ops, inp, block)
+    check_close(out, ref * k, f"mid kernel {shape}")
