@@ -128,6 +128,15 @@ bool tuned_int8_ok(const sglk_fused_experts_args* a) {
 }
 
 // bf16 fused_experts on the tuned bf16 kernel (gemm_bf16_256.hip): VNNI-2 packed weights, whole tiles, large M
+// bf16 experts below the 256-row kernel's range (< 44 rows per expert; at 64 rows the two measured the same, both bound by
+// the 1.2 GB of bf16 weights): weight-streaming kernel on the packed order (gemm_bf16_mid.hip), tiles of up to 96 rows
+bool mid_bf16_ok(const sglk_fused_experts_args* a) {
+    const int64_t S = (int64_t)a->M * a->topk;
+    return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
+           S < (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+           getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_BF16_MID") == nullptr;
+}
+
 bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 128 &&
@@ -199,8 +208,9 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     };
     const bool tuned = tuned_fp8_ok(a);
     const bool tuned_i8 = tuned_int8_ok(a);
-    const bool tuned_b16 = tuned_bf16_ok(a);
-    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM);
+    const bool mid_b16 = mid_bf16_ok(a);
+    const bool tuned_b16 = !mid_b16 && tuned_bf16_ok(a);
+    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (mid_b16 ? kMidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM));
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -389,6 +399,39 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         q2.topk = topk;
         q2.topk_weights = a->topk_weights;
         rc = launch_gemm_i8_256(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else if (mid_b16) {
+        BmidParams q1{};
+        q1.x = (const uint16_t*)a->hidden;
+        q1.x_stride = a->hidden_stride;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_expert_stride = (int64_t)2 * N * K * 2;
+        q1.out = ic1;                  // bf16 [position][N]
+        q1.out_stride = N;
+        q1.M = M; q1.N = N; q1.K = K;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.n_half = N;
+        rc = launch_moe_gemm_bf16_mid(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        BmidParams q2{};
+        q2.x = ic1;
+        q2.x_stride = N;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_expert_stride = (int64_t)K * N * 2;
+        q2.out = ic2;                  // bf16 [slot][K]
+        q2.out_stride = K;
+        q2.M = M * topk; q2.N = K; q2.K = N;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.topk_weights = a->topk_weights;
+        rc = launch_moe_gemm_bf16_mid(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else if (tuned_b16) {

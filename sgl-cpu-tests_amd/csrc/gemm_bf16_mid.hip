@@ -31,21 +31,32 @@ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; } 
 
 struct Ctx {
     int pos0, rows, ntile, kblocks, kb0, ksr;
-    const unsigned char* wp;      // lane's dword of (tile row, k pair 4g) in K block 0 of the range
+    const unsigned char* wp[2];   // lane's dword of (tile row, k pair 4g) in K block 0 of the range, per weight tile
 };
 
-template <int MT, int TM>
+// MODE: PLAIN = dense rows (split-K, bias); GATE_UP / DOWN = the two grouped GEMMs of bf16 fused_experts at small / mid batch
+// sizes (gather by sorted_slot, gate + up tile per wave with SiLU*mul in registers; routing weight + scatter by slot), same
+// contract as gemm_bf16_256.hip's modes (oracle /root/reference/test_moe.py:22-54).
+template <int MODE, int MT, int TM, bool ODD>
 SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     constexpr int kXBuf = TM * 256;
+    constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
     // one K block of the wave's tile = 4 k-steps x 4 k pairs; k pair kp of the block sits kp * 128 B further
-    auto load_block = [&](u32x4 (&dst)[4], int kb) __attribute__((always_inline)) {
-        const unsigned char* b = c.wp + (int64_t)kb * (64 * 128);
+    auto load_block = [&](u32x4 (&dst)[TPW][4], int kb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int a = 0; a < TPW; ++a) {
+            const unsigned char* b = c.wp[a] + (int64_t)kb * (64 * 128);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[s][j] = *reinterpret_cast<const unsigned*>(b + (s * 16 + j) * 128);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[a][s][j] = *reinterpret_cast<const unsigned*>(b + (s * 16 + j) * 128);
+        }
     };
-    u32x4 ring[2][4];
+    // DOWN: output slot and routing weight of the tile's rows start their two round trips here and wait in LDS
+    int my_slot = -1;
+    float my_tw = 0.f;
+    if (MODE == MODE_DOWN && (int)threadIdx.x < c.rows) my_slot = p.sorted_slot[c.pos0 + threadIdx.x];
+    u32x4 ring[2][TPW][4];
     load_block(ring[0], 0);
     load_block(ring[1], 1);
 
@@ -59,7 +70,10 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     for (int j = 0; j < XV; ++j) {
         const int row = (wave * XV + j) * 4 + (lane >> 4), ch = (lane & 15) ^ (row & 15);
         const int rr = row < c.rows ? row : c.rows - 1;     // padding rows re-read the last row; their outputs are dropped
-        xsrc[j] = p.x + (int64_t)(c.pos0 + rr) * p.x_stride + ch * 8 + (int64_t)c.kb0 * 128;
+        int64_t xrow;
+        if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[c.pos0 + rr] / p.topk) * p.x_stride;
+        else xrow = (int64_t)(c.pos0 + rr) * p.x_stride;
+        xsrc[j] = p.x + xrow + ch * 8 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
         unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
@@ -68,16 +82,20 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
             __builtin_amdgcn_global_load_lds((gptr_bm_t)(xsrc[j] + kb * 128), (lptr_bm_t)(dst + j * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[MT];
+    f32x4 acc[TPW][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < TPW; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[a][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
         if (prefetch_x) x_dma(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
-        bf16x8 w[4];
+        bf16x8 w[TPW][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) w[s] = __builtin_bit_cast(bf16x8, ring[half][s]);
+        for (int a = 0; a < TPW; ++a)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w[a][s] = __builtin_bit_cast(bf16x8, ring[half][a][s]);
         if (refill) load_block(ring[half], kb + 2);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* xb = lds + (kb & 1) * kXBuf;
@@ -88,26 +106,44 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (((s * 4 + g) ^ (xr & 15)) << 4));
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[s], x, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TPW; ++a) acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[a][s], x, acc[a][mt], 0, 0, 0);
             }
         }
         if (prefetch_x) {
-            if (refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16));   // all but the 16 refill loads: the DMA has landed
+            if (refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16 * TPW));   // all but the refill loads: the DMA has landed
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
             __builtin_amdgcn_s_barrier();
         }
     };
 
+    if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];
     x_dma(0);
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    int* slot_tab = reinterpret_cast<int*>(lds + 2 * kXBuf);
+    float* tw_tab = reinterpret_cast<float*>(lds + 2 * kXBuf + TM * 4);
+    if (MODE == MODE_DOWN && tid < TM) {
+        slot_tab[tid] = my_slot;
+        tw_tab[tid] = my_tw;
+    }
     __syncthreads();
     int kb = 0;
-    for (; kb + 2 < c.kblocks; kb += 2) {
+    if (!ODD) {   // parity of the block count = template parameter (both tails in one kernel cost registers)
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
+        block(kb, 0, false, true);
+        block(kb + 1, 1, false, false);
+    } else {                               // odd block counts (expert widths like 384): a three-block tail
+        for (; kb + 3 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
         block(kb, 0, true, true);
-        block(kb + 1, 1, true, true);
+        block(kb + 1, 1, false, true);
+        block(kb + 2, 0, false, false);
     }
-    block(kb, 0, false, true);
-    block(kb + 1, 1, false, false);
 
     const int q4 = g * 4;
     const int col = c.ntile * 128 + wave * 16 + q4;
@@ -115,7 +151,23 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     for (int mt = 0; mt < MT; ++mt) {
         const int tr = mt * 16 + r;
         if (tr >= c.rows) continue;
-        const f32x4 v4 = acc[mt];
+        if (MODE == MODE_GATE_UP) {
+            const f32x4 gt = acc[0][mt], up = acc[TPW - 1][mt];
+            uint2 v;
+            v.x = pack_bf16x2(silu_f32(gt[0]) * up[0], silu_f32(gt[1]) * up[1]);
+            v.y = pack_bf16x2(silu_f32(gt[2]) * up[2], silu_f32(gt[3]) * up[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + col) = v;
+            continue;
+        }
+        if (MODE == MODE_DOWN) {
+            const f32x4 v4 = acc[0][mt] * tw_tab[tr];
+            uint2 v;
+            v.x = pack_bf16x2(v4[0], v4[1]);
+            v.y = pack_bf16x2(v4[2], v4[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)slot_tab[tr] * p.out_stride + col) = v;
+            continue;
+        }
+        const f32x4 v4 = acc[0][mt];
         if (p.ksplit > 1) {
             float* dst = p.partial + ((int64_t)c.ksr * p.M + c.pos0 + tr) * p.N + col;
             *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
@@ -130,7 +182,7 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     }
 }
 
-template <int TM>
+template <int MODE, int TM, bool ODD>
 __global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(const BmidParams p) {
     constexpr int kTM = TM;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -138,7 +190,8 @@ __global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int n_tiles = p.N >> 7;
-    const int mtiles = (p.M + kTM - 1) / kTM;
+    const bool grouped = MODE != MODE_PLAIN;
+    const int mtiles = grouped ? p.num_tiles[0] : (p.M + kTM - 1) / kTM;
     const int live = mtiles * n_tiles * nsplit;
     if ((int)blockIdx.x >= live) return;
     const int Ls = xcd_remap(blockIdx.x, live);
@@ -146,20 +199,34 @@ __global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(co
     const int mtile = L / n_tiles;
     Ctx c;
     c.ntile = L - mtile * n_tiles;
-    c.pos0 = mtile * kTM;
-    c.rows = p.M - c.pos0 < kTM ? p.M - c.pos0 : kTM;
+    int e = 0;
+    if (grouped) {
+        const int4 ti = p.tile_info[mtile];
+        e = __builtin_amdgcn_readfirstlane(ti.x);
+        c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+        c.rows = __builtin_amdgcn_readfirstlane(ti.z);
+    } else {
+        c.pos0 = mtile * kTM;
+        c.rows = p.M - c.pos0 < kTM ? p.M - c.pos0 : kTM;
+    }
     c.ksr = Ls - L * nsplit;
     c.kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
     c.kb0 = c.ksr * c.kblocks;
     // weight row of this lane: tile row (lane & 15) of the wave's 16-row tile; k group g = lane >> 4 -> k pairs 4g .. 4g+3
-    const int R = c.ntile * 128 + wave * 16 + (lane & 15);
-    const int64_t dword = ((int64_t)(R >> 5) * (p.K >> 1) + (int64_t)c.kb0 * 64 + (lane >> 4) * 4) * 32 + (R & 31);
-    c.wp = p.w + dword * 4;
+    const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        // GATE_UP: tile 0 = gate rows, tile 1 = the matching up rows (N further); else one tile
+        const int R = (a && MODE == MODE_GATE_UP ? p.n_half : 0) + c.ntile * 128 + wave * 16 + (lane & 15);
+        const int64_t dword = ((int64_t)(R >> 5) * (p.K >> 1) + (int64_t)c.kb0 * 64 + (lane >> 4) * 4) * 32 + (R & 31);
+        c.wp[a] = wexp + dword * 4;
+    }
     const int mt = (c.rows + 15) >> 4;
-    if (mt <= 2) run<2, TM>(p, lds, c);
-    else if (TM == 64 || mt <= 4) run<4, TM>(p, lds, c);
-    else if (mt <= 6) run<(TM == 64 ? 4 : 6), TM>(p, lds, c);
-    else run<(TM == 64 ? 4 : 8), TM>(p, lds, c);
+    constexpr int MTMAX = TM / 16;
+    if (mt <= 2) run<MODE, 2, TM, ODD>(p, lds, c);
+    else if (MTMAX == 4 || mt <= 4) run<MODE, 4, TM, ODD>(p, lds, c);
+    else if (MTMAX == 6 || mt <= 6) run<MODE, (MTMAX >= 6 ? 6 : 4), TM, ODD>(p, lds, c);
+    else run<MODE, (MTMAX >= 8 ? 8 : 4), TM, ODD>(p, lds, c);
 }
 
 }  // namespace gbmid
@@ -184,14 +251,49 @@ int bf16_mid_ksplit(int M, int N, int K) {
 int launch_gemm_bf16_mid(const BmidParams& p, hipStream_t stream) {
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
-    if (p.K % 128 != 0 || p.N % 128 != 0 || kblocks < 2 || kblocks % 2 != 0 || (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial)))
+    if (p.K % 128 != 0 || p.N % 128 != 0 || kblocks < 2 || (nsplit > 1 && (kblocks % 2 != 0 || (p.K >> 7) != nsplit * kblocks || !p.partial)))
         SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_mid: N=%d K=%d with %d ranges not supported", p.N, p.K, nsplit);
     const int tm = p.M <= 64 ? 64 : 128;
     const int64_t blocks = (int64_t)ceil_div(p.M, tm) * (p.N >> 7) * nsplit;
     if (blocks == 0) return SGLK_OK;
-    if (tm == 64) hipLaunchKernelGGL(gbmid::gemm_bf16_mid_kernel<64>, dim3((unsigned)blocks), dim3(512), 2 * 64 * 256, stream, p);
-    else hipLaunchKernelGGL(gbmid::gemm_bf16_mid_kernel<128>, dim3((unsigned)blocks), dim3(512), 2 * 128 * 256, stream, p);
+    // split-K ranges are even by construction; an unsplit odd reduction takes the ODD build
+    const bool odd = (kblocks & 1) != 0;
+#define BMID_PLAIN(TMV, OD)                                                                                        \
+    {                                                                                                              \
+        static bool attr = false;                                                                                  \
+        const size_t lds = 2 * TMV * 256 + 2 * TMV * 4;                                                            \
+        if (!attr) {                                                                                               \
+            hipFuncSetAttribute((const void*)gbmid::gemm_bf16_mid_kernel<MODE_PLAIN, TMV, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_PLAIN, TMV, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
+    }
+    if (tm == 64) { if (odd) BMID_PLAIN(64, true) else BMID_PLAIN(64, false) }
+    else { if (odd) BMID_PLAIN(128, true) else BMID_PLAIN(128, false) }
+#undef BMID_PLAIN
     SGLK_CHECK_LAUNCH("gemm_bf16_mid");
+    return SGLK_OK;
+}
+
+// bf16 fused_experts below the 256-row kernel's range: tile table built with tile_m = 96 (kMidTileM); GATE_UP out = ic1
+// [position][N] (p.N = N, p.K = K, n_half = N), DOWN out = ic2 [slot][K] (p.N = K, p.K = N)
+int launch_moe_gemm_bf16_mid(int mode, const BmidParams& p, int max_mtiles, hipStream_t stream) {
+    const int kblocks = p.K >> 7;
+    if (p.K % 128 != 0 || p.N % 128 != 0 || kblocks < 2 || !p.tile_info || !p.num_tiles || !p.sorted_slot)
+        SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_bf16_mid: N=%d K=%d not supported", p.N, p.K);
+    const int64_t blocks = (int64_t)max_mtiles * (p.N >> 7);
+    if (blocks == 0) return SGLK_OK;
+    constexpr int TM = kMidTileM;
+    const size_t lds = 2 * TM * 256 + 2 * TM * 4;
+    const bool odd = (kblocks & 1) != 0;
+    if (mode == MODE_GATE_UP) {
+        if (odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    } else {
+        if (odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_DOWN, TM, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+        else hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_DOWN, TM, false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    }
+    SGLK_CHECK_LAUNCH("moe_gemm_bf16_mid");
     return SGLK_OK;
 }
 

@@ -148,7 +148,17 @@ struct BmidParams {
     int M, N, K;
     int ksplit, split_kblocks;   // K ranges of split_kblocks 128-wide blocks; <= 1: whole reduction
     float* partial;           // [ksplit][M][N] fp32
+    // grouped modes (bf16 fused_experts at small / mid batch sizes): N = weight rows of the launch's output (GATE_UP: the
+    // expert width, weights [E][2N][K]; DOWN: the hidden size), tile table built with tile_m = 96
+    int64_t w_expert_stride;  // bytes per expert
+    const int4* tile_info;
+    const int* num_tiles;
+    const int* sorted_slot;
+    int topk;
+    int n_half;               // GATE_UP: row offset of the "up" half
+    const float* topk_weights;   // DOWN
 };
+int launch_moe_gemm_bf16_mid(int mode, const BmidParams& p, int max_mtiles, hipStream_t stream);
 int bf16_mid_ksplit(int M, int N, int K);   // 0 = shape not taken, else the number of K ranges
 int launch_gemm_bf16_mid(const BmidParams& p, hipStream_t stream);
 

@@ -268,6 +268,32 @@ def test_fused_experts_bf16_on_tuned_kernel(ops, shape):
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("shape", [(200, 768, 2048, 16, 4), (4, 384, 1024, 32, 8), (150, 384, 640, 8, 2), (61, 256, 4352, 4, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_bf16_on_mid_kernel(ops, shape):
+    """Small / mid-size packed bf16 fused_experts (below ~72 rows per expert) runs on the weight-streaming kernel
+    csrc/gemm_bf16_mid.hip: even, odd (N = 384 -> 3, K = 640 -> 5) and long (K = 4352 -> 34) K-block counts, masked slots,
+    against the fp32 restatement of /root/reference/test_moe.py:22-54 and the generic engine; run-to-run bit identity."""
+    M, N, K, E, topk = shape
+    g = torch.Generator().manual_seed(6000 + M)
+    a = (torch.randn(M, K, generator=g) / 10).bfloat16()
+    w1 = (torch.randn(E, 2 * N, K, generator=g) / 10).bfloat16()
+    w2 = (torch.randn(E, K, N, generator=g) / 10).bfloat16()
+    tw, ids = moe.softmax_topk(torch.randn(M, E, generator=g).bfloat16(), topk, True)
+    ids = ids.clone()
+    ids[::5, 0] = -1
+    ref = moe.fused_experts_f32(a, w1, w2, tw, ids)
+    w1p, w2p = ops.convert_weight_packed(w1.cuda()), ops.convert_weight_packed(w2.cuda())
+    args = (tw.cuda(), ids.cuda(), False, False, False, None, None, None, None, None)
+    out = ops.fused_experts_cpu(a.cuda(), w1p, w2p, *args, True)
+    assert rel_rms(out, ref) < 6e-3
+    assert ref_pred(ref, out) or rel_rms(out, ref) < 4e-3
+    generic = ops.fused_experts_cpu(a.cuda(), w1.cuda(), w2.cuda(), *args, False)
+    assert rel_rms(out, generic) < 4e-3
+    again = ops.fused_experts_cpu(a.cuda(), w1p, w2p, *args, True)
+    assert torch.equal(out, again)
+
+
 def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):
     """Same fp8 fused_experts inputs through the tuned path and (forced) through the generic engine."""
     name, M, N, K, E, topk, bn, bk, masked, seed, full = recipes.MOE_FP8_CASES[1]
