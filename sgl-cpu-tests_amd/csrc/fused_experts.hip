@@ -120,6 +120,13 @@ bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
 // int8 fused_experts on the int8 matrix cores (gemm_i8_256.hip): packed weights, both reduction lengths whole 64-deep
 // stages (>= 4 of them), output tiles whole, and enough rows per expert for 256-token tiles to pay (same threshold as the
 // fp8 path).  32-bit buffer offsets bound the operand sizes.
+// int8 experts below the 256-row kernel's range: weight-streaming int8 kernel (gemm_i8_mid.hip), tiles of up to 128 rows
+bool mid_int8_ok(const sglk_fused_experts_args* a) {
+    const int64_t S = (int64_t)a->M * a->topk;
+    return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
+           S < (int64_t)44 * a->E && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr;
+}
+
 bool tuned_int8_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 256 &&
@@ -207,10 +214,11 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         if (tm) hipEventRecord(tm->at(call, i), s);
     };
     const bool tuned = tuned_fp8_ok(a);
-    const bool tuned_i8 = tuned_int8_ok(a);
+    const bool mid_i8 = mid_int8_ok(a);
+    const bool tuned_i8 = !mid_i8 && tuned_int8_ok(a);
     const bool mid_b16 = mid_bf16_ok(a);
     const bool tuned_b16 = !mid_b16 && tuned_bf16_ok(a);
-    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (mid_b16 ? kMidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM));
+    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -345,6 +353,58 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         if (rc != SGLK_OK) return rc;
         // join: the combine needs the tail tiles' rows of ic2 too
         if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream join failed");
+        mark(3);
+    } else if (mid_i8) {
+        // the same four steps as the 256-row int8 path below, with the weight-streaming kernel for the two GEMMs
+        int8_t* xq = (int8_t*)(ws + w.xq);
+        float* xs = (float*)(ws + w.xs);
+        rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q1{};
+        q1.x = xq;
+        q1.x_stride = K;
+        q1.x_scale = xs;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_bytes = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = 2 * N;
+        q1.out = ic1;                  // fp32 [position][N]
+        q1.out_stride = N;
+        q1.M = M;
+        q1.K = K;
+        q1.n_tiles = N / 128;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.n_half = N;
+        rc = launch_gemm_i8_mid(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        int8_t* hq = (int8_t*)(ws + w.ic1q);
+        float* hs = (float*)(ws + w.ic1s);
+        rc = launch_quant_int8_rows_f32((const float*)ic1, N, hq, N, hs, (int64_t)M * topk, N, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q2{};
+        q2.x = hq;
+        q2.x_stride = N;
+        q2.x_scale = hs;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_bytes = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = K;
+        q2.out = ic2;                  // bf16 [slot][K]
+        q2.out_stride = K;
+        q2.M = M * topk;
+        q2.K = N;
+        q2.n_tiles = K / 128;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.topk_weights = a->topk_weights;
+        rc = launch_gemm_i8_mid(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
         mark(3);
     } else if (tuned_i8) {
         // W8A8 on the int8 matrix cores: quantise x per token, GEMM-1 (+SiLU*mul, fp32 out), quantise ic1 per row,

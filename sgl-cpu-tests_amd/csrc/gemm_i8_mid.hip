@@ -1,0 +1,211 @@
+// Small / mid-batch int8 W8A8 fused_experts (below the 256-row kernel's range): the weight-streaming scheme of
+// moe_gemm_fp8w_mid.hip on the int8 matrix cores.  Oracle: /root/reference/test_moe_int8.py:16-94 (per-token dynamic
+// activation quantisation, i8 x i8 -> i32, (As * acc) * Bs).
+//
+// * tile = up to 128 rows x 16 (GATE_UP) or 8 (DOWN) weight row-tiles per workgroup of 8 waves; a wave owns the gate and the
+//   matching up tile (GATE_UP) or one tile (DOWN) for all the rows; MT = 4 or 8 column tiles of 16 rows by the tile's rows;
+// * weights never touch LDS: a packed piece (16 rows x 64 k = 1 KiB, pack.hip) is one global_load_dwordx4 per lane and IS the
+//   A operand of mfma_i32_16x16x64_i8; two 128-wide K blocks (four pieces per tile) are in flight per wave;
+// * the quantised activations go global -> LDS by DMA one K block at a time (rows x 128 B, 16-byte chunks XOR-swizzled by
+//   row & 7 on the source side), double buffered, one counted s_waitcnt (a builtin, so that the compiler's wait-count pass
+//   sees it) + one barrier per block;
+// * integer accumulation is exact; the epilogue applies (x_scale * acc) * w_scale in that order without contraction, like
+//   gemm_i8_256.hip, then SiLU*mul -> fp32 ic1 (GATE_UP) or the routing weight -> bf16 rows by slot (DOWN).
+#include "sglk_common.h"
+#include "moe_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace sglk {
+
+typedef const __attribute__((address_space(1))) void* gptr_im_t;
+typedef __attribute__((address_space(3))) void* lptr_im_t;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace gimid {
+
+constexpr int kTM = kI8MidTileM;      // 128 rows at most
+constexpr int kXBuf = kTM * 128;      // one K block of the row tile: 16 KiB
+constexpr int kLds = 2 * kXBuf;
+
+struct Ctx {
+    int pos0, rows, ntile, kblocks, e;
+    const unsigned char* wp[2];   // lane's 16 bytes inside the first piece of the wave's weight row-tiles
+    int row0[2];                  // first weight row of each tile (for the per-row scales)
+};
+
+template <int MODE, int MT, bool ODD>
+SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
+    constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
+    constexpr int PB = 2 * TPW;          // weight pieces per K block per wave
+    u32x4 ring[2 * PB];                  // slot = block*PB + tile*2 + k half
+#pragma unroll
+    for (int i = 0; i < 2 * PB; ++i)
+        ring[i] = *reinterpret_cast<const u32x4*>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int XV = MT / 4;           // 1-KiB DMA pieces (8 rows x 128 B) of a K block per wave: MT*16 rows / 8 / 8
+
+    const int8_t* xsrc[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const int row = (wave * XV + j) * 8 + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+        const int rr = row < c.rows ? row : c.rows - 1;   // padding rows re-read the last row; their outputs are dropped
+        int64_t xrow;
+        if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[c.pos0 + rr] / p.topk) * p.x_stride;
+        else xrow = (int64_t)(c.pos0 + rr) * p.x_stride;
+        xsrc[j] = p.x + xrow + ch * 16;
+    }
+    auto x_dma = [&](int kb) __attribute__((always_inline)) {
+        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+#pragma unroll
+        for (int j = 0; j < XV; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_im_t)(xsrc[j] + kb * 128), (lptr_im_t)(dst + j * 1024), 16, 0, 0);
+    };
+
+    i32x4 acc[TPW][MT];
+#pragma unroll
+    for (int a = 0; a < TPW; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[a][mt] = (i32x4){0, 0, 0, 0};
+
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
+        if (prefetch_x) x_dma(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        i32x4 w[TPW][2];
+#pragma unroll
+        for (int a = 0; a < TPW; ++a) {
+            w[a][0] = __builtin_bit_cast(i32x4, ring[half * PB + 2 * a]);
+            w[a][1] = __builtin_bit_cast(i32x4, ring[half * PB + 2 * a + 1]);
+        }
+        if (refill) {
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                ring[half * PB + j] = *reinterpret_cast<const u32x4*>(c.wp[j >> 1] + (int64_t)(2 * (kb + 2) + (j & 1)) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int xr = mt * 16 + r;
+            const unsigned char* base = xb + xr * 128;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const i32x4 x = *reinterpret_cast<const i32x4*>(base + (((s * 4 + g) ^ (xr & 7)) << 4));
+#pragma unroll
+                for (int a = 0; a < TPW; ++a) acc[a][mt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w[a][s], x, acc[a][mt], 0, 0, 0);
+            }
+        }
+        if (prefetch_x) {
+            if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB): all but the refills -> the DMA has landed
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+
+    x_dma(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    int kb = 0;
+    if (!ODD) {
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
+        block(kb, 0, false, true);
+        block(kb + 1, 1, false, false);
+    } else {
+        for (; kb + 3 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true);
+            block(kb + 1, 1, true, true);
+        }
+        block(kb, 0, true, true);
+        block(kb + 1, 1, false, true);
+        block(kb + 2, 0, false, false);
+    }
+
+    // ---- epilogue: lane holds weight rows 4g..4g+3 of each tile for row r of every column tile ----------------------------
+    const int q4 = g * 4;
+    const float* wsc = p.w_scale + (int64_t)c.e * p.scale_rows;
+    const float4 ws0 = *reinterpret_cast<const float4*>(wsc + c.row0[0] + q4);
+    const float4 ws1 = TPW == 2 ? *reinterpret_cast<const float4*>(wsc + c.row0[1] + q4) : ws0;
+    const int col = c.ntile * 128 + wave * 16 + q4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int tr = mt * 16 + r;
+        if (tr >= c.rows) continue;
+        if (MODE == MODE_GATE_UP) {
+            const int slot = p.sorted_slot[c.pos0 + tr];
+            const float xs = p.x_scale[slot / p.topk];
+            float4 v;
+            v.x = silu_f32(xs * (float)acc[0][mt][0] * ws0.x) * (xs * (float)acc[TPW - 1][mt][0] * ws1.x);
+            v.y = silu_f32(xs * (float)acc[0][mt][1] * ws0.y) * (xs * (float)acc[TPW - 1][mt][1] * ws1.y);
+            v.z = silu_f32(xs * (float)acc[0][mt][2] * ws0.z) * (xs * (float)acc[TPW - 1][mt][2] * ws1.z);
+            v.w = silu_f32(xs * (float)acc[0][mt][3] * ws0.w) * (xs * (float)acc[TPW - 1][mt][3] * ws1.w);
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (int64_t)(c.pos0 + tr) * p.out_stride + col) = v;
+        } else {
+            const int slot = p.sorted_slot[c.pos0 + tr];
+            const float xs = p.x_scale[c.pos0 + tr];
+            const float tw = p.topk_weights[slot];
+            float o4[4];
+            o4[0] = xs * (float)acc[0][mt][0] * ws0.x * tw;
+            o4[1] = xs * (float)acc[0][mt][1] * ws0.y * tw;
+            o4[2] = xs * (float)acc[0][mt][2] * ws0.z * tw;
+            o4[3] = xs * (float)acc[0][mt][3] * ws0.w * tw;
+            uint2 v;
+            v.x = pack_bf16x2(o4[0], o4[1]);
+            v.y = pack_bf16x2(o4[2], o4[3]);
+            *reinterpret_cast<uint2*>(p.out + (int64_t)slot * p.out_stride + col) = v;
+        }
+    }
+}
+
+template <int MODE, bool ODD>
+__global__ __launch_bounds__(512, 2) void gemm_i8_mid_kernel(const I8GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int live = p.num_tiles[0] * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int L = xcd_remap(blockIdx.x, live);
+    const int mtile = L / p.n_tiles;
+    const int4 ti = p.tile_info[mtile];
+    Ctx c;
+    c.e = __builtin_amdgcn_readfirstlane(ti.x);
+    c.ntile = L - mtile * p.n_tiles;
+    c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+    c.rows = __builtin_amdgcn_readfirstlane(ti.z);
+    c.kblocks = p.K >> 7;
+    const int ctiles = p.K >> 6;
+    // both modes: 128 output columns per workgroup, wave w -> columns ntile*128 + 16w .. +15 (GATE_UP: gate + matching up tile)
+    c.row0[0] = c.ntile * 128 + wave * 16;
+    c.row0[1] = (MODE == MODE_GATE_UP ? p.n_half : 0) + c.row0[0];
+    const unsigned char* wexp = p.w + (int64_t)c.e * p.w_bytes;
+    c.wp[0] = wexp + ((int64_t)(c.row0[0] >> 4) * ctiles) * 1024 + lane * 16;
+    c.wp[1] = wexp + ((int64_t)(c.row0[1] >> 4) * ctiles) * 1024 + lane * 16;
+    if (c.rows <= 64) run<MODE, 4, ODD>(p, lds, c);
+    else run<MODE, 8, ODD>(p, lds, c);
+}
+
+}  // namespace gimid
+
+// tile table built with tile_m = kI8MidTileM; GATE_UP: n_tiles = N / 128, out = fp32 ic1 [position][N]; DOWN: n_tiles = R / 128,
+// out = bf16 ic2 [slot][R]
+int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream) {
+    const int kblocks = p.K >> 7;
+    if (p.K % 128 != 0 || kblocks < 2 || !p.tile_info || !p.num_tiles || !p.sorted_slot || p.x_stride % 16 != 0)
+        SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_mid: K=%d not supported", p.K);
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks == 0) return SGLK_OK;
+    const bool odd = (kblocks & 1) != 0;
+    const size_t lds = gimid::kLds;
+#define I8MID(MD, OD) hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p)
+    if (mode == MODE_GATE_UP) { if (odd) I8MID(MODE_GATE_UP, true); else I8MID(MODE_GATE_UP, false); }
+    else { if (odd) I8MID(MODE_DOWN, true); else I8MID(MODE_DOWN, false); }
+#undef I8MID
+    SGLK_CHECK_LAUNCH("gemm_i8_mid");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

@@ -6,6 +6,7 @@ namespace sglk {
 
 constexpr int kTileM = 128;        // tokens (slot rows) per tile of the 128x128 kernel
 constexpr int kStreamTileM = 32;   // tokens per tile of the weight-streaming small-M kernel
+constexpr int kI8MidTileM = 128;   // rows per tile (at most) of the int8 weight-streaming kernel (gemm_i8_mid.hip)
 constexpr int kMidTileM = 96;      // tokens per tile (at most) of the weight-streaming mid-M kernel
 
 enum { MODE_GATE_UP = 0, MODE_DOWN = 1, MODE_PLAIN = 2 };   // PLAIN: out[pos] = x.W^T (+bias) (+addend*scale), dense
@@ -136,6 +137,9 @@ struct GenericGemmParams {
     int ksplit, split_stages, split_rows;
     float* partial;
 };
+
+// int8 W8A8 fused_experts at small / mid batch sizes, weight-streaming (gemm_i8_mid.hip); grouped modes only
+int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 
 // decode-size dense bf16 GEMM on packed (VNNI-2) weights, weight-streaming (gemm_bf16_mid.hip)
 struct BmidParams {

@@ -98,6 +98,33 @@ def test_fused_experts_int8_on_int8_mfma(ops, shape):
     assert torch.equal(out, again), "run-to-run bit identity"
 
 
+@pytest.mark.parametrize("shape", [(200, 768, 2048, 16, 4), (4, 384, 1024, 32, 8), (150, 384, 640, 8, 2), (61, 256, 4352, 4, 2),
+                                   (300, 256, 512, 8, 2)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_int8_on_mid_kernel(ops, shape):
+    """Small / mid-size packed int8 fused_experts (below 44 rows per expert) runs on the weight-streaming kernel
+    csrc/gemm_i8_mid.hip (mfma_i32_16x16x64_i8): even / odd / long K-block counts, tiles up to 128 rows, masked slots; the
+    reference's bars against the restated oracle, the generic engine, run-to-run bit identity."""
+    M, N, K, E, topk = shape
+    inp = recipes.moe_int8_inputs(M, N, K, E, topk, 4100 + M)
+    ids = inp["topk_ids"].clone()
+    ids[::7, 0] = -1
+    ref = moe.fused_experts_int8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["topk_weight"], ids).float()
+    d = cuda(inp)
+    idc = ids.cuda()
+    w1p, w2p = ops.convert_weight_packed(d["w1"]), ops.convert_weight_packed(d["w2"])
+    out = ops.fused_experts_cpu(d["a"].clone(), w1p, w2p, d["topk_weight"], idc, False, True, False, d["w1s"], d["w2s"],
+                                None, None, None, True)
+    mre = (out.float().cpu() - ref).abs().mean() / ref.abs().mean()
+    assert mre < 0.01, f"mean relative error {mre:.4f}"
+    assert ref_pred(ref, out)
+    generic = ops.fused_experts_cpu(d["a"].clone(), d["w1"], d["w2"], d["topk_weight"], idc, False, True, False, d["w1s"],
+                                    d["w2s"], None, None, None, False)
+    assert rel_rms(out, generic) < 5e-3
+    again = ops.fused_experts_cpu(d["a"].clone(), w1p, w2p, d["topk_weight"], idc, False, True, False, d["w1s"], d["w2s"],
+                                  None, None, None, True)
+    assert torch.equal(out, again), "run-to-run bit identity"
+
+
 # ---- shared_expert ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", recipes.SHARED_CASES, ids=lambda c: c[0])
 def test_shared_expert_bf16_and_int8(ops, case):
