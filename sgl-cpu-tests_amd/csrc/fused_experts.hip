@@ -337,7 +337,10 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.n_half = 0;
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
-        g2.n_tiles = (tile_m == 128 || tile_m == kMidTileM) ? K / 128 : K / 256;
+        // mid kernel, DOWN: two 128-column tiles per workgroup on one weight ring when the shapes allow (SGLK_MID_DOWN2=0: one)
+        const char* d2_env = getenv("SGLK_MID_DOWN2");
+        const bool mid_down2 = tile_m == kMidTileM && N % 256 == 0 && K % 256 == 0 && !(d2_env && d2_env[0] == '0');
+        g2.n_tiles = (tile_m == 128 || (tile_m == kMidTileM && !mid_down2)) ? K / 128 : K / 256;
         g2.out = ic2;
         g2.out_stride = K;
         g2.topk_weights = a->topk_weights;
@@ -348,7 +351,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_DOWN, g2, max_tiles, s)
                                     : launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s))
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)
-             : tile_m == kMidTileM    ? launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s)
+             : tile_m == kMidTileM    ? (mid_down2 ? launch_moe_gemm_fp8w_mid_down2(g2, max_tiles, s)
+                                                    : launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s))
                                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         // join: the combine needs the tail tiles' rows of ic2 too

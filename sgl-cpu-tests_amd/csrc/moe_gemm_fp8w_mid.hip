@@ -227,6 +227,126 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     }
 }
 
+// DOWN over TWO neighbouring column tiles (2 x 128 output columns) of one m-tile per workgroup, even block counts: the weight
+// ring runs straight from the first tile's last K blocks into the second tile's first ones, so the pair pays ONE prologue and
+// one ring fill (a DOWN tile at N = 768 is only six blocks long); the activations are simply streamed through LDS twice.
+template <int MT>
+SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
+    int my_slot = -1;
+    float my_tw = 0.f;
+    if ((int)threadIdx.x < c.rows) my_slot = p.sorted_slot[c.pos0 + threadIdx.x];
+    const int nk = c.kblocks;
+    // virtual block vb = tile * nk + kb; c.wp[0] / c.wp[1] = the wave's row tile in the first / second column tile
+    auto wptr = [&](int vb) __attribute__((always_inline)) {
+        const bool second = vb >= nk;
+        return (second ? c.wp[1] : c.wp[0]) + (int64_t)(2 * (second ? vb - nk : vb)) * 1024;
+    };
+    u32x4 ring[4];   // slot = (block & 1) * 2 + k half
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(wptr(i >> 1) + (i & 1) * 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    constexpr int XV = MT / 2;
+    const uint16_t* xsrc[XV];
+#pragma unroll
+    for (int j = 0; j < XV; ++j) {
+        const int row = (wave * XV + j) * 4 + (lane >> 4), ch = (lane & 15) ^ (row & 15);
+        const int rr = row < c.rows ? row : c.rows - 1;
+        xsrc[j] = p.x + (int64_t)(c.pos0 + rr) * p.x_stride + ch * 8;
+    }
+    auto x_dma = [&](int buf, int kb) __attribute__((always_inline)) {
+        unsigned char* dst = lds + buf * kXBuf + wave * XV * 1024;
+#pragma unroll
+        for (int j = 0; j < XV; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + kb * 128), (lptr_t)(dst + j * 1024), 16, 0, 0);
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // block kb of column tile `tile` (virtual block vb = tile * nk + kb; nk is even, so vb & 1 == kb & 1 == half)
+    auto block = [&](int tile, int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
+        const int vb = tile * nk + kb;
+        if (prefetch_x) x_dma(half ^ 1, kb + 1 == nk ? 0 : kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 w[4];
+        {
+            const u32x4 r0 = ring[half * 2], r1 = ring[half * 2 + 1];
+            w[0] = cvt8(r0[0], r0[1]);
+            w[1] = cvt8(r0[2], r0[3]);
+            w[2] = cvt8(r1[0], r1[1]);
+            w[3] = cvt8(r1[2], r1[3]);
+        }
+        if (refill) {
+            const unsigned char* nx = wptr(vb + 2);
+            ring[half * 2] = *reinterpret_cast<const u32x4*>(nx);
+            ring[half * 2 + 1] = *reinterpret_cast<const u32x4*>(nx + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float sc = c.sc[tile * kMaxKB + kb];
+        const unsigned char* xb = lds + half * kXBuf;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int xr = mt * 16 + r;
+            const unsigned char* base = xb + xr * 256;
+            bf16x8 x[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) x[s] = *reinterpret_cast<const bf16x8*>(base + (((s * 4 + g) ^ (xr & 15)) << 4));
+            f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[s], x[s], t, 0, 0, 0);
+            acc[mt] += sc * t;
+        }
+        if (prefetch_x) {
+            if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | 2);   // vmcnt(2): all but the two refills -> the DMA has landed
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+        }
+    };
+    auto store = [&](int tile) __attribute__((always_inline)) {
+        const int* slot_tab = reinterpret_cast<const int*>(lds + kRowTabOff);
+        const float* tw_tab = reinterpret_cast<const float*>(lds + kRowTabOff + kTM * 4);
+        const int col = (c.ntile * 2 + tile) * 128 + wave * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int tr = mt * 16 + r;
+            if (tr < c.rows) {
+                const f32x4 v4 = acc[mt] * tw_tab[tr];
+                uint2 v;
+                v.x = pack_bf16x2(v4[0], v4[1]);
+                v.y = pack_bf16x2(v4[2], v4[3]);
+                *reinterpret_cast<uint2*>(p.out + (int64_t)slot_tab[tr] * p.out_stride + col) = v;
+            }
+            acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    if (my_slot >= 0) my_tw = p.topk_weights[my_slot];
+    x_dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    if (tid < kTM) {
+        reinterpret_cast<int*>(lds + kRowTabOff)[tid] = my_slot;
+        reinterpret_cast<float*>(lds + kRowTabOff + kTM * 4)[tid] = my_tw;
+    }
+    __syncthreads();
+    // first column tile: every block refills (the stream continues into the second tile) and prefetches (block nk-1 fetches
+    // the activations' block 0 again)
+    for (int kb = 0; kb < nk; kb += 2) {
+        block(0, kb, 0, true, true);
+        block(0, kb + 1, 1, true, true);
+    }
+    store(0);
+    int kb = 0;
+    for (; kb + 2 < nk; kb += 2) {
+        block(1, kb, 0, true, true);
+        block(1, kb + 1, 1, true, true);
+    }
+    block(1, kb, 0, false, true);
+    block(1, kb + 1, 1, false, false);
+    store(1);
+}
+
 template <int MODE, bool ODD>
 __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -291,7 +411,63 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp
     else run<MODE, 6, ODD>(p, lds, c);
 }
 
+// DOWN, two column tiles per workgroup (p.n_tiles = output columns / 256)
+__global__ __launch_bounds__(512, 4) void moe_gemm_fp8w_mid_down2_kernel(const MoeGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int live = p.num_tiles[0] * p.n_tiles;
+    if ((int)blockIdx.x >= live) return;
+    const int L = xcd_remap(blockIdx.x, live);
+    const int mtile = L / p.n_tiles;
+    const int4 ti = p.tile_info[mtile];
+    const int e = __builtin_amdgcn_readfirstlane(ti.x);
+    TileCtx c;
+    c.ntile = L - mtile * p.n_tiles;
+    c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+    c.rows = __builtin_amdgcn_readfirstlane(ti.z);
+    c.kblocks = p.C >> 7;
+    c.kb0 = 0;
+    c.ksr = 0;
+    const int ctiles = p.C >> 6;
+    c.row16[0] = c.ntile * 16 + wave;        // first column tile: columns ntile*256 + 16 wave ..
+    c.row16[1] = c.row16[0] + 8;             // second: 128 columns further
+    const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
+    c.wp[0] = wexp + ((int64_t)c.row16[0] * ctiles) * 1024 + lane * 16;
+    c.wp[1] = wexp + ((int64_t)c.row16[1] * ctiles) * 1024 + lane * 16;
+    float* sc = reinterpret_cast<float*>(lds + kScOff) + wave * (2 * kMaxKB);
+    {
+        const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int srow = (c.row16[a] * 16) / p.block_n;
+            sc[a * kMaxKB + lane] = lane < c.kblocks ? scale_e[srow * p.scale_cols + lane] : 0.f;
+        }
+    }
+    c.sc = sc;
+    const int mt = (c.rows + 15) >> 4;
+    if (mt <= 2) run_down2<2>(p, lds, c);
+    else if (mt <= 4) run_down2<4>(p, lds, c);
+    else run_down2<6>(p, lds, c);
+}
+
 }  // namespace gmid
+
+// DOWN with two column tiles per workgroup: even K-block counts and an even number of 128-column tiles
+int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
+    const int kblocks = p.C >> 7;
+    if (p.C % 256 != 0 || kblocks < 2 || kblocks > gmid::kMaxKB) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid_down2: reduction length %d", p.C);
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks == 0) return SGLK_OK;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_down2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmid::kLds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_down2_kernel, dim3((unsigned)blocks), dim3(512), gmid::kLds, stream, p);
+    SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid_down2");
+    return SGLK_OK;
+}
 
 int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
     const int nsplit = (mode == MODE_PLAIN && p.ksplit > 1) ? p.ksplit : 1;

@@ -190,6 +190,8 @@ int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles
 // up to 128-token tiles, weights streamed global -> VGPR, activations K block by K block through LDS
 // (moe_gemm_fp8w_mid.hip); tile table built with tile_m = 128
 int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+// DOWN with two neighbouring column tiles per workgroup (p.n_tiles = output columns / 256; reduction % 256 == 0)
+int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
 // moe_align with a second tile table: an expert's last tile lands in tile_info_b when it has at most tail_max rows
 // (tail_max <= 0: exactly sglk_moe_align)
