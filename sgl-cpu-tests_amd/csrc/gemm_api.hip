@@ -63,6 +63,8 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
         if (km > ks) ks = km;
         const int kb = bf16_mid_ksplit(M, N, K);
         if (kb > ks) ks = kb;
+        const int ki = i8_mid_ksplit(M, N, K);
+        if (ki > ks) ks = ki;
         if (ks > 1) w.partial = take((size_t)ks * M * N * 4);
     }
     w.total = off;
@@ -345,6 +347,44 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         q.K = K;
         q.n_tiles = N / 256;
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
+    }
+    // W8A8 at decode sizes (M <= 128): weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)
+    if (a->wtype == SGLK_W_INT8 && a->packed && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr) {
+        const int ks = i8_mid_ksplit(M, N, K);
+        if (ks >= 1) {
+            const int8_t* xq = (const int8_t*)a->x;
+            int64_t xq_stride = a->x_stride;
+            const float* xs = a->x_scale;
+            if (quant_here) {
+                rc = launch_quant_int8_rows((const uint16_t*)a->x, a->x_stride, (int8_t*)(ws + w.xq), K, (float*)(ws + w.xs),
+                                            M, K, 1e-10f, s);
+                if (rc != SGLK_OK) return rc;
+                xq = (const int8_t*)(ws + w.xq);
+                xq_stride = K;
+                xs = (const float*)(ws + w.xs);
+            }
+            if (xq_stride % 16 == 0 && ((uintptr_t)xq % 16) == 0) {
+                I8GemmParams q{};
+                q.x = xq;
+                q.x_stride = xq_stride;
+                q.x_scale = xs;
+                q.w = (const uint8_t*)a->w;
+                q.w_bytes = (int64_t)N * K;
+                q.w_scale = a->w_scale;
+                q.scale_rows = N;
+                q.bias = a->bias;
+                q.out = (uint16_t*)a->out;
+                q.out_stride = a->out_stride;
+                q.out_type = a->out_type;
+                q.M = M;
+                q.N = N;
+                q.K = K;
+                q.ksplit = ks;
+                q.split_kblocks = (K >> 7) / ks;
+                q.partial_i32 = ks > 1 ? (int32_t*)(ws + w.partial) : nullptr;
+                return launch_gemm_i8_mid_plain(q, s);
+            }
+        }
     }
     // W8A8 on the int8 matrix cores (exact int32 accumulation): packed int8 weights, large M
     if (a->wtype == SGLK_W_INT8 && a->packed && M >= 192 && N % 256 == 0 && K % 64 == 0 && K >= 256 && a->out_type == SGLK_OUT_BF16 &&

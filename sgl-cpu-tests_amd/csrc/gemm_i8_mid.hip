@@ -29,7 +29,7 @@ constexpr int kXBuf = kTM * 128;      // one K block of the row tile: 16 KiB
 constexpr int kLds = 2 * kXBuf;
 
 struct Ctx {
-    int pos0, rows, ntile, kblocks, e;
+    int pos0, rows, ntile, kblocks, e, kb0, ksr;
     const unsigned char* wp[2];   // lane's 16 bytes inside the first piece of the wave's weight row-tiles
     int row0[2];                  // first weight row of each tile (for the per-row scales)
 };
@@ -55,7 +55,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
         int64_t xrow;
         if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[c.pos0 + rr] / p.topk) * p.x_stride;
         else xrow = (int64_t)(c.pos0 + rr) * p.x_stride;
-        xsrc[j] = p.x + xrow + ch * 16;
+        xsrc[j] = p.x + xrow + ch * 16 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
         unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
@@ -135,7 +135,27 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     for (int mt = 0; mt < MT; ++mt) {
         const int tr = mt * 16 + r;
         if (tr >= c.rows) continue;
-        if (MODE == MODE_GATE_UP) {
+        if (MODE == MODE_PLAIN) {
+            if (p.ksplit > 1) {   // exact int32 partial of this K range; scales, bias and the rounding belong to the reduce
+                int32_t* dst = p.partial_i32 + ((int64_t)c.ksr * p.M + c.pos0 + tr) * p.N + col;
+                *reinterpret_cast<i32x4*>(dst) = acc[0][mt];
+            } else {
+                const float xs = p.x_scale[c.pos0 + tr];
+                float o4[4];
+                o4[0] = xs * (float)acc[0][mt][0] * ws0.x;
+                o4[1] = xs * (float)acc[0][mt][1] * ws0.y;
+                o4[2] = xs * (float)acc[0][mt][2] * ws0.z;
+                o4[3] = xs * (float)acc[0][mt][3] * ws0.w;
+                if (p.bias) { o4[0] += p.bias[col]; o4[1] += p.bias[col + 1]; o4[2] += p.bias[col + 2]; o4[3] += p.bias[col + 3]; }
+                const int64_t o = (int64_t)(c.pos0 + tr) * p.out_stride + col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (p.out_type == SGLK_OUT_F32) reinterpret_cast<float*>(p.out)[o + i] = o4[i];
+                    else if (p.out_type == SGLK_OUT_F16) reinterpret_cast<_Float16*>(p.out)[o + i] = (_Float16)o4[i];
+                    else p.out[o + i] = f32_to_bf16_bits(o4[i]);
+                }
+            }
+        } else if (MODE == MODE_GATE_UP) {
             const int slot = p.sorted_slot[c.pos0 + tr];
             const float xs = p.x_scale[slot / p.topk];
             float4 v;
@@ -166,29 +186,93 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_mid_kernel(const I8GemmParams 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int live = p.num_tiles[0] * p.n_tiles;
+    const int nsplit = (MODE == MODE_PLAIN && p.ksplit > 1) ? p.ksplit : 1;
+    // PLAIN (dense): the row tiles are rows [128 i, 128 i + 128) of M rows, one "expert"
+    const int mtiles = MODE == MODE_PLAIN ? (p.M + kTM - 1) / kTM : p.num_tiles[0];
+    const int live = mtiles * p.n_tiles * nsplit;
     if ((int)blockIdx.x >= live) return;
-    const int L = xcd_remap(blockIdx.x, live);
+    const int Ls = xcd_remap(blockIdx.x, live);
+    const int L = Ls / nsplit;
     const int mtile = L / p.n_tiles;
-    const int4 ti = p.tile_info[mtile];
+    int4 ti;
+    if (MODE == MODE_PLAIN) ti = make_int4(0, mtile * kTM, p.M - mtile * kTM < kTM ? p.M - mtile * kTM : kTM, 0);
+    else ti = p.tile_info[mtile];
     Ctx c;
     c.e = __builtin_amdgcn_readfirstlane(ti.x);
     c.ntile = L - mtile * p.n_tiles;
     c.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     c.rows = __builtin_amdgcn_readfirstlane(ti.z);
-    c.kblocks = p.K >> 7;
+    c.ksr = Ls - L * nsplit;
+    c.kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
+    c.kb0 = c.ksr * c.kblocks;
     const int ctiles = p.K >> 6;
     // both modes: 128 output columns per workgroup, wave w -> columns ntile*128 + 16w .. +15 (GATE_UP: gate + matching up tile)
     c.row0[0] = c.ntile * 128 + wave * 16;
     c.row0[1] = (MODE == MODE_GATE_UP ? p.n_half : 0) + c.row0[0];
     const unsigned char* wexp = p.w + (int64_t)c.e * p.w_bytes;
-    c.wp[0] = wexp + ((int64_t)(c.row0[0] >> 4) * ctiles) * 1024 + lane * 16;
-    c.wp[1] = wexp + ((int64_t)(c.row0[1] >> 4) * ctiles) * 1024 + lane * 16;
+    c.wp[0] = wexp + ((int64_t)(c.row0[0] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
+    c.wp[1] = wexp + ((int64_t)(c.row0[1] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
     if (c.rows <= 64) run<MODE, 4, ODD>(p, lds, c);
     else run<MODE, 8, ODD>(p, lds, c);
 }
 
+// out[r][c] = cast((x_scale[r] * (float)(sum over ranges of the int32 partials)) * w_scale[c] + bias[c]): the integer sum is
+// exact, the float operations are the oracle's, in its order (/root/reference/test_gemm_int8.py:25-47)
+__global__ __launch_bounds__(256) void i8_splitk_reduce_kernel(const I8GemmParams p) {
+    const int64_t total = (int64_t)p.M * p.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / p.N;
+        const int cidx = (int)(i - r * p.N);
+        int32_t acc = 0;
+        for (int k = 0; k < p.ksplit; ++k) acc += p.partial_i32[((int64_t)k * p.M + r) * p.N + cidx];
+        float v = p.x_scale[r] * (float)acc * p.w_scale[cidx];
+        if (p.bias) v += p.bias[cidx];
+        if (p.out_type == SGLK_OUT_F32) reinterpret_cast<float*>(p.out)[r * p.out_stride + cidx] = v;
+        else if (p.out_type == SGLK_OUT_F16) reinterpret_cast<_Float16*>(p.out)[r * p.out_stride + cidx] = (_Float16)v;
+        else p.out[r * p.out_stride + cidx] = f32_to_bf16_bits(v);
+    }
+}
+
 }  // namespace gimid
+
+// decode-size dense W8A8: one row tile (M <= 128), 128 output columns per workgroup, equal even K ranges until ~512 workgroups
+int i8_mid_ksplit(int M, int N, int K) {
+    if (M <= 0 || M > gimid::kTM || N % 128 != 0 || K % 256 != 0) return 0;
+    const int kblocks = K >> 7;
+    const int64_t tiles = N / 128;
+    const int per_min = kblocks >= 4 ? 4 : 2;
+    int best = 0;
+    for (int per = kblocks; per >= per_min; per -= 2) {
+        if (kblocks % per != 0) continue;
+        const int ks = kblocks / per;
+        if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
+        best = ks;
+        if (tiles * ks >= 512) break;
+    }
+    return best;
+}
+
+int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
+    const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
+    if (p.K % 128 != 0 || p.N % 128 != 0 || p.M > gimid::kTM || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
+        (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial_i32)))
+        SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_mid(plain): M=%d N=%d K=%d with %d ranges not supported", p.M, p.N, p.K, nsplit);
+    if (p.M == 0) return SGLK_OK;
+    I8GemmParams q = p;
+    q.n_tiles = p.N >> 7;
+    q.scale_rows = p.N;
+    const int64_t blocks = (int64_t)q.n_tiles * nsplit;
+    hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MODE_PLAIN, false>), dim3((unsigned)blocks), dim3(512), gimid::kLds, stream, q);
+    SGLK_CHECK_LAUNCH("gemm_i8_mid(plain)");
+    if (nsplit > 1) {
+        int64_t rb = ceil_div((int64_t)p.M * p.N, 256);
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(gimid::i8_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, q);
+        SGLK_CHECK_LAUNCH("gemm_i8_mid(reduce)");
+    }
+    return SGLK_OK;
+}
 
 // tile table built with tile_m = kI8MidTileM; GATE_UP: n_tiles = N / 128, out = fp32 ic1 [position][N]; DOWN: n_tiles = R / 128,
 // out = bf16 ic2 [slot][R]

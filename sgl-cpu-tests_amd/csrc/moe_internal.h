@@ -73,6 +73,11 @@ struct I8GemmParams {
     int topk;
     int n_half;               // GATE_UP: N = row offset of the up half of w1
     const float* topk_weights;   // DOWN
+    // PLAIN on the weight-streaming kernel (decode-size dense W8A8, gemm_i8_mid.hip): N output columns, K ranges of
+    // split_kblocks 128-wide blocks with exact int32 partials [range][M][N] (ksplit <= 1: whole reduction, direct output)
+    int N, ksplit, split_kblocks;
+    int32_t* partial_i32;
+    int out_type;             // PLAIN: SGLK_OUT_* of `out`
 };
 int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 
@@ -140,6 +145,9 @@ struct GenericGemmParams {
 
 // int8 W8A8 fused_experts at small / mid batch sizes, weight-streaming (gemm_i8_mid.hip); grouped modes only
 int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
+// decode-size dense W8A8 (M <= 128): 0 = shape not taken, else the number of K ranges; the launch includes the exact reduce
+int i8_mid_ksplit(int M, int N, int K);
+int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream);
 
 // decode-size dense bf16 GEMM on packed (VNNI-2) weights, weight-streaming (gemm_bf16_mid.hip)
 struct BmidParams {

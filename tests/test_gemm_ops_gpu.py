@@ -220,10 +220,13 @@ def test_int8_gemm_ops(ops, case):
             assert torch.equal(outp, out)
 
 
-@pytest.mark.parametrize("shape", [(192, 256, 256, False), (1000, 512, 1024, True), (300, 768, 4160, True), (2049, 1536, 2048, False)],
+@pytest.mark.parametrize("shape", [(192, 256, 256, False), (1000, 512, 1024, True), (300, 768, 4160, True), (2049, 1536, 2048, False),
+                                   (1, 256, 512, True), (64, 512, 1024, True), (128, 256, 4096, False), (37, 1536, 7168, True)],
                          ids=lambda s: "x".join(map(str, s[:3])))
 def test_int8_mfma_gemm_is_exact(ops, shape):
-    """Large-M packed int8 GEMM runs on mfma_i32_32x32x32_i8 (csrc/gemm_i8_256.hip): the integer dot products are exact,
+    """Packed int8 GEMMs run on the int8 matrix cores -- mfma_i32_32x32x32_i8 (csrc/gemm_i8_256.hip) for M >= 192, the
+    weight-streaming mfma_i32_16x16x64_i8 kernel with exact int32 split-K partials (csrc/gemm_i8_mid.hip) for M <= 128 where the
+    shape allows: the integer dot products are exact,
     so the result must equal an exact-integer evaluation of the oracle's expression (As * C * Bs + bias, fp32, one bf16
     rounding; /root/reference/test_gemm_int8.py:41-47) BIT FOR BIT, and the reference predicate against the float oracle."""
     M, N, K, has_bias = shape
