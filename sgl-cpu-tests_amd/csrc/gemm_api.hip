@@ -57,6 +57,13 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
             w.ic1s = take((size_t)M * 4);
         }
     }
+    if (need_ic1) {    // shared expert at decode sizes on the weight-streaming kernel: partials of both GEMMs share one buffer
+        const int k1 = mid_dense_ksplit(M, 2 * N, K), k2 = mid_dense_ksplit(M, K, N);
+        if (k1 >= 1 && k2 >= 1) {
+            const size_t b1 = (size_t)k1 * M * 2 * N * 4, b2 = (size_t)k2 * M * K * 4;
+            w.partial = take(b1 > b2 ? b1 : b2);
+        }
+    }
     if (!need_ic1) {   // plain dense GEMM: fp32 partials of the split-K form (small M)
         int ks = generic_ksplit(M, N, K);
         const int km = mid_dense_ksplit(M, N, K);          // fp8 / bf16 small-M paths (largest of the plans)
@@ -163,6 +170,51 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
         t2.addend_stride = a->fused_out_stride;
         t2.addend_scale = a->routed_scaling_factor;
         return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t2, t256, s);
+    }
+    // fp8, decode-size M: both GEMMs as split-K passes of the weight-streaming kernel; the gate_up partials are reduced by a
+    // SiLU*mul pass (fp32 until the single bf16 rounding of ic1, like the fused path), the down partials by the ordered reduce
+    // that also adds fused_out * routed_scaling_factor
+    if (a->wtype == SGLK_W_FP8_E4M3 && (a->packed & 3) == 3 && a->block_k == 128 && a->block_n > 0 && a->block_n % 16 == 0 &&
+        a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        const int k1 = mid_dense_ksplit(M, 2 * N, K), k2 = mid_dense_ksplit(M, K, N);
+        if (k1 >= 1 && k2 >= 1) {
+            float* partial = (float*)(ws + w.partial);
+            const int mt = (int)ceil_div(M, kMidTileM);
+            MoeGemmParams t1{};
+            fill_tuned(t1, a->hidden, a->hidden_stride, M, nullptr, a->w1, a->w1_scale, 2 * N, K, a->block_n, nullptr, nullptr);
+            t1.n_tiles = 2 * N / 128;
+            t1.ksplit = k1;
+            t1.split_kblocks = (K >> 7) / k1;
+            t1.split_rows = M;
+            t1.out_cols = 2 * N;
+            t1.partial = partial;
+            rc = launch_moe_gemm_fp8w_mid(MODE_PLAIN, t1, mt, s);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_splitk_reduce_silu_mul(partial, k1, M, N, ic1, N, s);
+            if (rc != SGLK_OK) return rc;
+            MoeGemmParams t2{};
+            fill_tuned(t2, ic1, N, M, nullptr, a->w2, a->w2_scale, K, N, a->block_n, nullptr, nullptr);
+            t2.n_tiles = K / 128;
+            t2.ksplit = k2;
+            t2.split_kblocks = (N >> 7) / k2;
+            t2.split_rows = M;
+            t2.out_cols = K;
+            t2.partial = partial;
+            rc = launch_moe_gemm_fp8w_mid(MODE_PLAIN, t2, mt, s);
+            if (rc != SGLK_OK) return rc;
+            GenericGemmParams r{};
+            r.partial = partial;
+            r.ksplit = k2;
+            r.split_rows = M;
+            r.n_out = K;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.addend = a->fused_out;
+            r.addend_stride = a->fused_out_stride;
+            r.addend_scale = a->routed_scaling_factor;
+            return launch_splitk_reduce(r, s);
+        }
     }
     const int tiles = (int)ceil_div(M, kGenericTileM);
     rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);

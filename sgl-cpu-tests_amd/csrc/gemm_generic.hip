@@ -321,7 +321,37 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GenericGemmPar
     }
 }
 
+// shared expert, small M: ic1[r][c] = bf16(silu(sum_k P[k][r][c]) * sum_k P[k][r][n + c]) from the fp32 partials of the
+// gate_up GEMM (2n columns), ranges summed in order
+__global__ __launch_bounds__(256) void splitk_reduce_silu_mul_kernel(const float* __restrict__ partial, int ksplit, int rows, int n,
+                                                                     unsigned short* __restrict__ out, int64_t out_stride) {
+    const int64_t total = (int64_t)rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int c = (int)(i - r * n);
+        float g = 0.f, u = 0.f;
+        for (int k = 0; k < ksplit; ++k) {
+            const float* row = partial + ((int64_t)k * rows + r) * (2 * n);
+            g += row[c];
+            u += row[n + c];
+        }
+        out[r * out_stride + c] = f32_to_bf16_bits(silu_f32(g) * u);
+    }
+}
+
 }  // namespace gg
+
+int launch_splitk_reduce_silu_mul(const float* partial, int ksplit, int rows, int n, uint16_t* out, int64_t out_stride,
+                                  hipStream_t stream) {
+    const int64_t total = (int64_t)rows * n;
+    if (total == 0) return SGLK_OK;
+    int64_t rb = ceil_div(total, 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(gg::splitk_reduce_silu_mul_kernel, dim3((unsigned)rb), dim3(256), 0, stream, partial, ksplit, rows, n,
+                       out, out_stride);
+    SGLK_CHECK_LAUNCH("split-K reduce (SiLU*mul)");
+    return SGLK_OK;
+}
 
 // Split-K plan: small-M dense GEMMs put only ceil(M/64) * ceil(N/64) workgroups on 256 CUs and each walks the whole
 // reduction with one synchronous load per stage; cutting K lifts the number of workgroups to ~512.  Ranges are whole

@@ -203,7 +203,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         } else if (MODE == MODE_PLAIN) {
             const int col = c.ntile * 128 + wave * 16 + q4;
             const f32x4 v4 = acc[0][mt];
-            if (p.ksplit > 1) {   // fp32 partial of this K range; bias and the bf16 rounding belong to the ordered reduce
+            if (p.partial) {      // fp32 partial of this K range; bias and the bf16 rounding belong to the ordered reduce
                 float* dst = p.partial + ((int64_t)c.ksr * p.split_rows + c.pos0 + tr) * p.out_cols + col;
                 *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
             } else {
@@ -476,7 +476,8 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.C >> 7;
     if (p.C % 128 != 0 || kblocks < 2 || kblocks > gmid::kMaxKB || (nsplit > 1 && (p.C >> 7) != nsplit * kblocks))
         SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid: reduction length %d / K range of %d blocks not supported", p.C, kblocks);
-    if (nsplit > 1 && (!p.partial || p.out_cols <= 0)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_mid: split-K without a partial buffer");
+    if ((nsplit > 1 && !p.partial) || (p.partial && (p.out_cols <= 0 || p.split_rows <= 0)))
+        SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_mid: split-K without a partial buffer");
     const size_t lds = gmid::kLds;
 #define MID_LAUNCH2(MD, OD)                                                                                        \
     {                                                                                                              \

@@ -181,6 +181,9 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
 // the ordered reduce of split-K partials alone (fields used: partial, ksplit, split_rows, n_out, out, out_type, out_stride,
 // bias, addend*)
 int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream);
+// ic1 = bf16(silu(gate) * up) from the fp32 split-K partials [range][rows][2n] of a gate_up GEMM
+int launch_splitk_reduce_silu_mul(const float* partial, int ksplit, int rows, int n, uint16_t* out, int64_t out_stride,
+                                  hipStream_t stream);
 // split-K plan of a small-M fp8 dense GEMM on the mid kernel: 0 = shape not taken, else the number of K ranges (>= 1)
 int mid_dense_ksplit(int M, int N, int K);
 // m-tile table of a dense problem (one "expert"); identity_slots (optional, [M]) = 0..M-1 for the tuned kernels' row lookup

@@ -210,6 +210,23 @@ def bench_gemm():
                  roofline_frac=round(flop / ms / 1e9 / peak, 4), peak_tflops=peak, bound="mfma")
 
 
+def bench_shared():
+    """shared_expert_cpu fp8 (/root/reference/test_moe_fp8.py:87-88) at a DeepSeek-like shape (hidden 7168, width 2048), decode
+    and prefill sizes; bytes = the two fp8 weight matrices."""
+    N, K = 2048, 7168
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w1 = ops.convert_weight_packed((torch.randn(2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    w2 = ops.convert_weight_packed((torch.randn(K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
+    s1 = torch.rand(2 * N // 128, K // 128, device="cuda", generator=g) * 1e-4
+    s2 = torch.rand(K // 128, N // 128, device="cuda", generator=g) * 1e-4
+    for M in (1, 16, 64, 128, 2048):
+        hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        ms = timed(lambda i: ops.shared_expert_cpu(hs, w1, w2, fo, 2.5, False, False, True, s1, s2, [128, 128], None, None, True), 20)
+        byts, flop = 3 * N * K, 6 * M * N * K
+        emit(op="shared_expert_fp8", M=M, N=N, K=K, ms=round(ms, 4), gbps=round(byts / ms / 1e6, 1), tflops=round(flop / ms / 1e9, 2))
+
+
 def bench_mxfp4():
     """mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py): W4A16, weights expanded to bf16 in the loader.  Small M is bound
     by the weight bytes (N*K/2 + scales), large M by the bf16 matrix cores; bmm_cpu rides along (test_bmm_fp8.py:131-132)."""
@@ -331,7 +348,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_offload": bench_moe_offload, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_offload": bench_moe_offload, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "shared": bench_shared, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()
