@@ -58,7 +58,10 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
         }
     }
     if (need_ic1) {    // shared expert at decode sizes on the weight-streaming kernel: partials of both GEMMs share one buffer
-        const int k1 = mid_dense_ksplit(M, 2 * N, K), k2 = mid_dense_ksplit(M, K, N);
+        int k1 = mid_dense_ksplit(M, 2 * N, K), k2 = mid_dense_ksplit(M, K, N);
+        const int j1 = bf16_mid_ksplit(M, 2 * N, K), j2 = bf16_mid_ksplit(M, K, N);    // bf16 weights: same scheme
+        if (j1 > k1) k1 = j1;
+        if (j2 > k2) k2 = j2;
         if (k1 >= 1 && k2 >= 1) {
             const size_t b1 = (size_t)k1 * M * 2 * N * 4, b2 = (size_t)k2 * M * K * 4;
             w.partial = take(b1 > b2 ? b1 : b2);
@@ -201,6 +204,48 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
             t2.out_cols = K;
             t2.partial = partial;
             rc = launch_moe_gemm_fp8w_mid(MODE_PLAIN, t2, mt, s);
+            if (rc != SGLK_OK) return rc;
+            GenericGemmParams r{};
+            r.partial = partial;
+            r.ksplit = k2;
+            r.split_rows = M;
+            r.n_out = K;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.addend = a->fused_out;
+            r.addend_stride = a->fused_out_stride;
+            r.addend_scale = a->routed_scaling_factor;
+            return launch_splitk_reduce(r, s);
+        }
+    }
+    // bf16 packed weights, decode sizes: the same four launches on the bf16 weight-streaming kernel
+    if (a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        const int k1 = bf16_mid_ksplit(M, 2 * N, K), k2 = bf16_mid_ksplit(M, K, N);
+        if (k1 >= 1 && k2 >= 1) {
+            float* partial = (float*)(ws + w.partial);
+            BmidParams q1{};
+            q1.x = (const uint16_t*)a->hidden;
+            q1.x_stride = a->hidden_stride;
+            q1.w = (const uint8_t*)a->w1;
+            q1.M = M; q1.N = 2 * N; q1.K = K;
+            q1.ksplit = k1;
+            q1.split_kblocks = (K >> 7) / k1;
+            q1.partial = partial;
+            rc = launch_gemm_bf16_mid(q1, s);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_splitk_reduce_silu_mul(partial, k1, M, N, ic1, N, s);
+            if (rc != SGLK_OK) return rc;
+            BmidParams q2{};
+            q2.x = ic1;
+            q2.x_stride = N;
+            q2.w = (const uint8_t*)a->w2;
+            q2.M = M; q2.N = K; q2.K = N;
+            q2.ksplit = k2;
+            q2.split_kblocks = (N >> 7) / k2;
+            q2.partial = partial;
+            rc = launch_gemm_bf16_mid(q2, s);
             if (rc != SGLK_OK) return rc;
             GenericGemmParams r{};
             r.partial = partial;

@@ -168,7 +168,7 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
             continue;
         }
         const f32x4 v4 = acc[0][mt];
-        if (p.ksplit > 1) {
+        if (p.partial) {
             float* dst = p.partial + ((int64_t)c.ksr * p.M + c.pos0 + tr) * p.N + col;
             *reinterpret_cast<float4*>(dst) = make_float4(v4[0], v4[1], v4[2], v4[3]);
         } else {

@@ -225,6 +225,14 @@ def bench_shared():
         ms = timed(lambda i: ops.shared_expert_cpu(hs, w1, w2, fo, 2.5, False, False, True, s1, s2, [128, 128], None, None, True), 20)
         byts, flop = 3 * N * K, 6 * M * N * K
         emit(op="shared_expert_fp8", M=M, N=N, K=K, ms=round(ms, 4), gbps=round(byts / ms / 1e6, 1), tflops=round(flop / ms / 1e9, 2))
+    b1 = ops.convert_weight_packed((torch.randn(2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
+    b2 = ops.convert_weight_packed((torch.randn(K, N, device="cuda", generator=g) * 0.02).bfloat16())
+    for M in (1, 64, 128):
+        hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+        fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+        ms = timed(lambda i: ops.shared_expert_cpu(hs, b1, b2, fo, 2.5, False, False, False, None, None, None, None, None, True), 20)
+        emit(op="shared_expert_bf16", M=M, N=N, K=K, ms=round(ms, 4), gbps=round(6 * N * K / ms / 1e6, 1),
+             tflops=round(6 * M * N * K / ms / 1e9, 2))
 
 
 def bench_mxfp4():
