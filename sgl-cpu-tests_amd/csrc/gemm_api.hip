@@ -62,6 +62,9 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
         const int j1 = bf16_mid_ksplit(M, 2 * N, K), j2 = bf16_mid_ksplit(M, K, N);    // bf16 weights: same scheme
         if (j1 > k1) k1 = j1;
         if (j2 > k2) k2 = j2;
+        const int i1 = i8_mid_ksplit(M, 2 * N, K), i2 = i8_mid_ksplit(M, K, N);      // int8 weights: int32 partials, same size
+        if (i1 > k1) k1 = i1;
+        if (i2 > k2) k2 = i2;
         if (k1 >= 1 && k2 >= 1) {
             const size_t b1 = (size_t)k1 * M * 2 * N * 4, b2 = (size_t)k2 * M * K * 4;
             w.partial = take(b1 > b2 ? b1 : b2);
@@ -217,6 +220,54 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
             r.addend_stride = a->fused_out_stride;
             r.addend_scale = a->routed_scaling_factor;
             return launch_splitk_reduce(r, s);
+        }
+    }
+    // int8 W8A8, decode sizes (M <= 128): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
+    // (fp32 ic1), quantise ic1, down as int32 partials, reduce with the scales + fused_out * routed_scaling_factor
+    if (i8 && (a->packed & 3) == 3 && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr) {
+        const int k1 = i8_mid_ksplit(M, 2 * N, K), k2 = i8_mid_ksplit(M, K, N);
+        if (k1 >= 1 && k2 >= 1) {
+            int32_t* partial = (int32_t*)(ws + w.partial);
+            int8_t* xq = (int8_t*)(ws + w.xq);
+            float* xs = (float*)(ws + w.xs);
+            rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+            if (rc != SGLK_OK) return rc;
+            I8GemmParams q1{};
+            q1.x = xq;
+            q1.x_stride = K;
+            q1.x_scale = xs;
+            q1.w = (const uint8_t*)a->w1;
+            q1.w_bytes = (int64_t)2 * N * K;
+            q1.w_scale = a->w1_scale;
+            q1.M = M; q1.N = 2 * N; q1.K = K;
+            q1.ksplit = k1;
+            q1.split_kblocks = (K >> 7) / k1;
+            q1.partial_i32 = partial;
+            q1.out = nullptr;
+            rc = launch_gemm_i8_mid_plain(q1, s);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_i8_reduce_silu_mul(partial, k1, M, N, xs, a->w1_scale, (float*)ic1, s);
+            if (rc != SGLK_OK) return rc;
+            int8_t* hq = (int8_t*)(ws + w.ic1q);
+            float* hs = (float*)(ws + w.ic1s);
+            rc = launch_quant_int8_rows_f32((const float*)ic1, N, hq, N, hs, M, N, 1e-7f, s);
+            if (rc != SGLK_OK) return rc;
+            I8GemmParams q2{};
+            q2.x = hq;
+            q2.x_stride = N;
+            q2.x_scale = hs;
+            q2.w = (const uint8_t*)a->w2;
+            q2.w_bytes = (int64_t)K * N;
+            q2.w_scale = a->w2_scale;
+            q2.M = M; q2.N = K; q2.K = N;
+            q2.ksplit = k2;
+            q2.split_kblocks = (N >> 7) / k2;
+            q2.partial_i32 = partial;
+            q2.out = nullptr;
+            rc = launch_gemm_i8_mid_plain(q2, s);
+            if (rc != SGLK_OK) return rc;
+            return launch_i8_reduce_addend(partial, k2, M, K, hs, a->w2_scale, (const uint16_t*)a->fused_out, a->fused_out_stride,
+                                           a->routed_scaling_factor, (uint16_t*)a->out, a->out_stride, s);
         }
     }
     // bf16 packed weights, decode sizes: the same four launches on the bf16 weight-streaming kernel

@@ -136,7 +136,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
         const int tr = mt * 16 + r;
         if (tr >= c.rows) continue;
         if (MODE == MODE_PLAIN) {
-            if (p.ksplit > 1) {   // exact int32 partial of this K range; scales, bias and the rounding belong to the reduce
+            if (p.partial_i32) {  // exact int32 partial of this K range; scales, bias and the rounding belong to the reduce
                 int32_t* dst = p.partial_i32 + ((int64_t)c.ksr * p.M + c.pos0 + tr) * p.N + col;
                 *reinterpret_cast<i32x4*>(dst) = acc[0][mt];
             } else {
@@ -233,7 +233,70 @@ __global__ __launch_bounds__(256) void i8_splitk_reduce_kernel(const I8GemmParam
     }
 }
 
+// shared expert, gate_up: ic1[r][c] = silu((xs[r] * (float)G) * ws[c]) * ((xs[r] * (float)U) * ws[n + c]) in fp32, G / U = the
+// exact int32 sums of the gate / up column over the K ranges (/root/reference/test_shared_experts.py:11-53 through the int8
+// linear of test_gemm_int8.py:25-47)
+__global__ __launch_bounds__(256) void i8_splitk_reduce_silu_mul_kernel(const int32_t* __restrict__ partial, int ksplit, int rows,
+                                                                        int n, const float* __restrict__ xs,
+                                                                        const float* __restrict__ ws, float* __restrict__ out) {
+    const int64_t total = (int64_t)rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int c = (int)(i - r * n);
+        int32_t g = 0, u = 0;
+        for (int k = 0; k < ksplit; ++k) {
+            const int32_t* row = partial + ((int64_t)k * rows + r) * (2 * n);
+            g += row[c];
+            u += row[n + c];
+        }
+        const float gv = xs[r] * (float)g * ws[c], uv = xs[r] * (float)u * ws[n + c];
+        out[r * n + c] = silu_f32(gv) * uv;
+    }
+}
+
+// shared expert, down: out[r][c] = bf16((xs[r] * (float)S) * ws[c] + addend[r][c] * scale)
+__global__ __launch_bounds__(256) void i8_splitk_reduce_addend_kernel(const int32_t* __restrict__ partial, int ksplit, int rows, int n,
+                                                                      const float* __restrict__ xs, const float* __restrict__ ws,
+                                                                      const unsigned short* __restrict__ addend, int64_t addend_stride,
+                                                                      float addend_scale, unsigned short* __restrict__ out,
+                                                                      int64_t out_stride) {
+    const int64_t total = (int64_t)rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int c = (int)(i - r * n);
+        int32_t acc = 0;
+        for (int k = 0; k < ksplit; ++k) acc += partial[((int64_t)k * rows + r) * n + c];
+        float v = xs[r] * (float)acc * ws[c];
+        if (addend) v += bf16_bits_to_f32(addend[r * addend_stride + c]) * addend_scale;
+        out[r * out_stride + c] = f32_to_bf16_bits(v);
+    }
+}
+
 }  // namespace gimid
+
+int launch_i8_reduce_silu_mul(const int32_t* partial, int ksplit, int rows, int n, const float* xs, const float* ws, float* out,
+                              hipStream_t stream) {
+    const int64_t total = (int64_t)rows * n;
+    if (total == 0) return SGLK_OK;
+    int64_t rb = ceil_div(total, 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(gimid::i8_splitk_reduce_silu_mul_kernel, dim3((unsigned)rb), dim3(256), 0, stream, partial, ksplit, rows, n, xs, ws, out);
+    SGLK_CHECK_LAUNCH("int8 split-K reduce (SiLU*mul)");
+    return SGLK_OK;
+}
+
+int launch_i8_reduce_addend(const int32_t* partial, int ksplit, int rows, int n, const float* xs, const float* ws,
+                            const uint16_t* addend, int64_t addend_stride, float addend_scale, uint16_t* out, int64_t out_stride,
+                            hipStream_t stream) {
+    const int64_t total = (int64_t)rows * n;
+    if (total == 0) return SGLK_OK;
+    int64_t rb = ceil_div(total, 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL(gimid::i8_splitk_reduce_addend_kernel, dim3((unsigned)rb), dim3(256), 0, stream, partial, ksplit, rows, n, xs, ws,
+                       addend, addend_stride, addend_scale, out, out_stride);
+    SGLK_CHECK_LAUNCH("int8 split-K reduce (addend)");
+    return SGLK_OK;
+}
 
 // decode-size dense W8A8: one row tile (M <= 128), 128 output columns per workgroup, equal even K ranges until ~512 workgroups
 int i8_mid_ksplit(int M, int N, int K) {
@@ -256,7 +319,7 @@ int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
     if (p.K % 128 != 0 || p.N % 128 != 0 || p.M > gimid::kTM || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
-        (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial_i32)))
+        (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial_i32)) || (!p.out && !p.partial_i32))
         SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_mid(plain): M=%d N=%d K=%d with %d ranges not supported", p.M, p.N, p.K, nsplit);
     if (p.M == 0) return SGLK_OK;
     I8GemmParams q = p;
@@ -265,7 +328,7 @@ int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
     const int64_t blocks = (int64_t)q.n_tiles * nsplit;
     hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MODE_PLAIN, false>), dim3((unsigned)blocks), dim3(512), gimid::kLds, stream, q);
     SGLK_CHECK_LAUNCH("gemm_i8_mid(plain)");
-    if (nsplit > 1) {
+    if (nsplit > 1 && p.out) {   // p.out == nullptr: the caller reduces the partials itself (shared expert)
         int64_t rb = ceil_div((int64_t)p.M * p.N, 256);
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(gimid::i8_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, q);

@@ -147,7 +147,12 @@ struct GenericGemmParams {
 int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 // decode-size dense W8A8 (M <= 128): 0 = shape not taken, else the number of K ranges; the launch includes the exact reduce
 int i8_mid_ksplit(int M, int N, int K);
-int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream);
+int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream);   // p.out == nullptr: partials only (no reduce)
+int launch_i8_reduce_silu_mul(const int32_t* partial, int ksplit, int rows, int n, const float* xs, const float* ws, float* out,
+                              hipStream_t stream);
+int launch_i8_reduce_addend(const int32_t* partial, int ksplit, int rows, int n, const float* xs, const float* ws,
+                            const uint16_t* addend, int64_t addend_stride, float addend_scale, uint16_t* out, int64_t out_stride,
+                            hipStream_t stream);
 
 // decode-size dense bf16 GEMM on packed (VNNI-2) weights, weight-streaming (gemm_bf16_mid.hip)
 struct BmidParams {
