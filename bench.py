@@ -39,7 +39,8 @@ PEAK_HBM_GBS = 8000.0
 
 
 def make_inputs(M, E_local, dev, seed):
-    """Bounded test-style data (/root/reference/test_moe_fp8_ext.py:96-112): raw randn scales overflow under reuse."""
+    """Bounded test-style data (/root/reference/test_moe_fp8_ext.py:96-112): raw randn scales overflow under reuse.
+    Returns the UNPACKED weights; the caller packs them (and may keep a host copy for the oracle check)."""
     g = torch.Generator(device=dev).manual_seed(seed)
     a = (torch.randn(M, K_HIDDEN, device=dev, generator=g) / K_HIDDEN ** 0.5).bfloat16()
     w1 = (torch.randn(E_local, 2 * N_INTER, K_HIDDEN, device=dev, generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
@@ -85,6 +86,11 @@ def main():
                     help="tokens per GPU per step (BASELINE.md evaluates the MFMA roofline at M = 16384)")
     ap.add_argument("--cpu-tokens", type=int, default=int(os.environ.get("SGLK_BENCH_CPU_TOKENS", 32768)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-a8", dest="a8", action="store_false",
+                    help="skip the secondary measurement of the opt-in a8 mode (fp8 activations, block-scaled fp8 MFMA)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step's output")
+    ap.add_argument("--out-of-place", dest="inplace", action="store_false",
+                    help="inplace=False (the default is the reference's inplace=True, bench_moe.py:113-130)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -115,8 +121,15 @@ def main():
     LCLONES = 2   # rotate over clones like bench_moe.py:50-58; 2 x 604 MB at N=1 exceeds the 256 MiB Infinity Cache
     a, w1, w2, w1s, w2s, tw, ids = make_inputs(M, E_local, dev, 1111 + rank)
     w1p, w2p = ops.convert_weight_packed(w1), ops.convert_weight_packed(w2)
+    verify = world == 1 and not args.no_verify
+    w_host = (w1.cpu(), w2.cpu()) if verify else None    # the oracle check after the timed region reads the plain weights
     del w1, w2
-    inputs = [a.clone() for _ in range(LCLONES)]
+    # inplace=True is the reference's call (bench_moe.py:113-130): every step overwrites its input.  So that no step ever
+    # reads a previous step's OUTPUT (values would drift towards 0 / inf and the chip clocks differently on such data), each
+    # step gets an input clone of its own (67 MB each at M = 16384; at most 96 of them, then they are reused).
+    prime = max(0, 12 - args.warmup)
+    n_inputs = min(96, prime + args.warmup + args.steps) if (args.inplace and world == 1) else LCLONES
+    inputs = [a.clone() for _ in range(n_inputs)]
     w1ps = [w1p.clone() for _ in range(LCLONES)]
     w2ps = [w2p.clone() for _ in range(LCLONES)]
     del w1p, w2p
@@ -129,19 +142,22 @@ def main():
         return ops.fused_experts_cpu(h, w1ps[i], w2ps[i], w, local_ids, False, False, True, w1s, w2s, BLOCK,
                                      None, None, True)
 
+    last = {}
     if world == 1:
         def step():
             i = step_idx[0] % LCLONES
-            out = ops.fused_experts_cpu(inputs[i], w1ps[i], w2ps[i], tw, ids, False, False, True, w1s, w2s, BLOCK,
+            j = step_idx[0] % n_inputs
+            out = ops.fused_experts_cpu(inputs[j], w1ps[i], w2ps[i], tw, ids, args.inplace, False, True, w1s, w2s, BLOCK,
                                         None, None, True)
             step_idx[0] += 1
+            last["out"] = out
             return out
     else:
         from sgl_kernel.expert_parallel import ExpertParallelMoE
         ep = ExpertParallelMoE(N_EXPERTS, local_experts)
 
         def step():
-            out = ep(inputs[step_idx[0] % LCLONES], tw, ids)
+            out = ep(inputs[step_idx[0] % n_inputs], tw, ids)
             step_idx[0] += 1
             return out
 
@@ -174,7 +190,6 @@ def main():
     # a power-management transient (a cold chip boosts, overshoots down, then settles: GEMM-1 0.74 -> 0.99 -> 0.79 ms,
     # profiles/r01_v7_kernel_stats.csv), so a short run would time the transient instead of the steady state it reports.
     # These steps are not counted as warm-up or timed steps; their number is printed in the result line.
-    prime = max(0, 12 - args.warmup)
     run_steps(prime)
     run_steps(args.warmup)
     barrier()
@@ -191,25 +206,116 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
-    ms = (ctypes.c_float * _lib.NUM_STAGES)()
-    calls = ctypes.c_int32(0)
-    _lib.check(L.sglk_stage_timer_read(timer, ms, ctypes.byref(calls)), "stage_timer_read")
-    stage_ms = {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}
-    # rows the local GEMM-1 launch processed per call (EP: received valid slots; = M*topk per rank on average)
-    gemm1_ms = float(ms[1])
+    def read_stages():
+        ms = (ctypes.c_float * _lib.NUM_STAGES)()
+        calls = ctypes.c_int32(0)
+        _lib.check(L.sglk_stage_timer_read(timer, ms, ctypes.byref(calls)), "stage_timer_read")
+        return [float(v) for v in ms], int(calls.value)
+
+    ms, n_calls = read_stages()
+    stage_ms = {n: round(ms[i], 4) for i, n in enumerate(_lib.STAGE_NAMES)}
+
+    def bench_a8():
+        """Secondary measurement, never the headline: the same workload in the opt-in a8 mode (activations quantised per
+        token x 128 block to e4m3 with power-of-two scales, both GEMMs on v_mfma_scale_f32_32x32x64_f8f6f4).  Its numerics are
+        NOT the reference's W8A16; the stated tolerance is against an oracle that quantises exactly as the kernels do."""
+        PEAK_FP8 = 5000.0
+        _ops.set_fp8_activations(True)
+        try:
+            run_steps(6)
+            torch.cuda.synchronize()
+            L.sglk_stage_timer_reset(timer)
+            _ops.set_stage_timer(timer)
+            t0 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps
+            _ops.set_stage_timer(None)
+            ms8, calls8 = read_stages()
+            p8 = _ops.last_path
+            if not (p8 & _lib.PATH_FP8_ACT):
+                raise RuntimeError(f"a8 kernels did not run (path {p8:#x})")
+            res = {"value": round(M * FLOP_PER_TOKEN / dt / 1e12, 2), "unit": "TFLOP/s", "ms_per_step": round(dt * 1e3, 4),
+                   "frac_of_5PF": round(M * FLOP_PER_TOKEN / dt / 1e12 / PEAK_FP8, 4),
+                   "gemm1_tflops": round(M * GEMM1_FLOP_PER_TOKEN / (ms8[1] * 1e-3) / 1e12, 2) if ms8[1] > 0 else None,
+                   "gemm1_frac_of_5PF": round(M * GEMM1_FLOP_PER_TOKEN / (ms8[1] * 1e-3) / 1e12 / PEAK_FP8, 4) if ms8[1] > 0 else None,
+                   "stage_ms": {n: round(ms8[i], 4) for i, n in enumerate(_lib.STAGE_NAMES)}, "launches": calls8,
+                   "mode": "opt-in (SGLK_FP8_ACT=1 / set_fp8_activations): e4m3 activations, per token x 128-block "
+                           "power-of-two scales, block-scaled fp8 MFMA; quantisation pass inside the align stage"}
+            if verify:
+                from oracle import moe_a8
+                n_s = 64
+                sample = torch.arange(0, M, max(1, M // n_s), device=dev)[:n_s]
+                ref_q = moe_a8.fused_experts_a8(a[sample].cpu(), w_host[0], w_host[1], w1s.cpu(), w2s.cpu(), BLOCK,
+                                                tw[sample].cpu(), ids[sample].cpu())
+                got = last["out"][sample].cpu().float()
+                rel_q = ((got - ref_q).norm() / ref_q.norm().clamp_min(1e-12)).item()
+                from oracle import c_oracle
+                ref = c_oracle.fused_experts_fp8(a[sample].cpu(), w_host[0], w_host[1], w1s.cpu(), w2s.cpu(), BLOCK,
+                                                 tw[sample].cpu(), ids[sample].cpu())
+                rel = ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+                res["tolerance"] = {"stated": "relative RMS < 2e-2 against the quantised-arithmetic oracle (oracle/moe_a8.py)",
+                                    "rel_rms_vs_quantised_oracle": round(rel_q, 5), "ok": rel_q < 2e-2,
+                                    "rel_rms_vs_w8a16_oracle": round(rel, 5),
+                                    "reference_predicate_vs_w8a16_oracle": bool(
+                                        torch.allclose(ref.bfloat16(), got.bfloat16(), rtol=1e-2, atol=1e-2)),
+                                    "rows": int(sample.numel())}
+            return res
+        finally:
+            _ops.set_stage_timer(None)
+            _ops.set_fp8_activations(False)
+    path = _ops.last_path          # which kernels the timed calls ran (reported by the C-ABI, not assumed)
+
+    def path_text(p):
+        tile = p & _lib.PATH_TILE_MASK
+        kern = {256: "g256i::moe_gemm_fp8w_256i_kernel", 96: "gmid::moe_gemm_fp8w_mid_kernel",
+                32: "gstream::moe_gemm_fp8w_stream_kernel", 128: "moe_gemm_fp8w_kernel (128-row)"}.get(tile, f"tile {tile}")
+        if p & _lib.PATH_FP8_ACT:
+            kern = "ga8::moe_gemm_a8_kernel"
+        return kern, tile
+
+    # ---- oracle check of the LAST timed step's output (outside the timed region): >= 64 token rows through the plain-C
+    #      oracle with the very same weights; the reference's predicate (utils.compare) + this repo's stated bound ----
+    verified = None
+    if rank == 0 and verify:
+        from oracle import c_oracle
+        n_s = 96
+        sample = torch.arange(0, M, max(1, M // n_s), device=dev)[:n_s]
+        ref = c_oracle.fused_experts_fp8(a[sample].cpu(), w_host[0], w_host[1], w1s.cpu(), w2s.cpu(), BLOCK,
+                                         tw[sample].cpu(), ids[sample].cpu())
+        got = last["out"][sample].cpu()
+        diff = (got.float() - ref).abs().max().item()
+        rel = ((got.float() - ref).norm() / ref.norm().clamp_min(1e-12)).item()
+        ok = bool(torch.allclose(ref.bfloat16(), got, rtol=1e-2, atol=1e-2)) and rel < 6e-3
+        verified = {"ok": ok, "rows": int(sample.numel()), "max_abs_diff": round(diff, 6), "rel_rms": round(rel, 6),
+                    "against": "oracle/c/moe_fp8_ref.c on the last timed step's output; predicate allclose(rtol=atol=1e-2) "
+                               "(/root/reference/utils.py:9-13) and relative RMS < 6e-3"}
 
     if rank == 0:
         total_tokens = M * world
         ms_per_step = elapsed / args.steps * 1e3
         tflops = total_tokens * FLOP_PER_TOKEN / (elapsed / args.steps) / 1e12
-        gemm1_tflops = M * GEMM1_FLOP_PER_TOKEN / (gemm1_ms * 1e-3) / 1e12 if gemm1_ms > 0 else 0.0
-        traffic = None
+        kern, tile = path_text(path)
+        tails_beside = bool(path & _lib.PATH_TAILS_AUX)
+        if tails_beside:
+            # the tail tiles' GEMM-1 -> GEMM-2 chain runs beside both big launches on the aux stream and is joined before the
+            # combine, so only the two GEMM stages TOGETHER have a well-defined duration
+            dom_ms, dom_flop = ms[1] + ms[2], M * FLOP_PER_TOKEN
+            dom_name = f"{kern}<GATE_UP> + <DOWN> (tail tiles beside on the aux stream: the two GEMM stages together)"
+        else:
+            dom_ms, dom_flop = ms[1], M * GEMM1_FLOP_PER_TOKEN
+            dom_name = f"{kern}<GATE_UP> (GEMM-1 + SiLU*mul), {tile}-row tiles" + \
+                       (", persistent" if path & _lib.PATH_PERSIST_G1 else ", one workgroup per tile")
+        dom_tflops = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not tails_beside:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("tokens") == M and tj.get("n_gpus", 1) == world:
                     traffic = tj.get("gemm1_hbm_bytes_per_launch")
+                    traffic_src = tj.get("source", "profiles/traffic.json") + " (separate rocprofv3 --pmc passes of this " \
+                        "command, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run)"
             except Exception:
                 traffic = None
         line = {
@@ -220,22 +326,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"fused_experts fp8-w8a16 block[128,128], Qwen3-30B-A3B experts "
                                    f"(K={K_HIDDEN}, N={N_INTER}, E={N_EXPERTS}, top-{TOPK}), {M} tokens per GPU per step, "
-                                   f"inplace=False, {LCLONES} rotating weight/input clones",
+                                   f"inplace={args.inplace and world == 1} (bench_moe.py:113-130), {LCLONES} rotating weight "
+                                   f"clones, {n_inputs} input clones",
                        "tokens_per_gpu": M, "experts_per_gpu": E_local, "priming_steps_before_warmup": prime,
                        "parallelism": "single GPU" if world == 1 else
                        (f"ep{world} (RCCL all-to-all dispatch/combine" +
                         (f", {len(streams)} steps in flight on separate HIP streams)" if streams else ")")
                         if backend == "nccl" else
                         f"ep{world} REHEARSAL over {backend}, host-staged payloads, ranks sharing GPUs: not a measurement")},
-            "roofline": {"bound": "mfma", "kernel": "g256i::moe_gemm_fp8w_256i_kernel<GATE_UP> (GEMM-1 + SiLU*mul)",
-                         "achieved": round(gemm1_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm1_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "launches": int(calls.value), "avg_launch_ms": round(gemm1_ms, 4),
-                         "algorithmic_flop_per_launch": M * GEMM1_FLOP_PER_TOKEN,
+            "verified": verified["ok"] if verified else None,
+            "verification": verified,
+            "roofline": {"bound": "mfma", "kernel": dom_name,
+                         "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "launches": n_calls, "avg_launch_ms": round(dom_ms, 4),
+                         "algorithmic_flop_per_launch": dom_flop,
                          "note": "W8A16: fp8 weights are converted exactly to bf16 in registers and multiplied on "
                                  "bf16 MFMA, so the dense bf16 peak (2.5 PF) is the governing roof"},
             "stage_ms": stage_ms,
         }
+        if world == 1 and args.a8:
+            try:
+                line["a8"] = bench_a8()
+            except Exception as e:
+                line["a8"] = {"value": None, "error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_tokens)

@@ -12,7 +12,10 @@
  *   - every pointer is a DEVICE pointer unless the name says host; the caller owns all memory, including the
  *     workspace (query the size with the matching *_workspace_bytes function; 256-byte aligned);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
- *     synchronises, allocates or frees (hipGraph-capture safe);
+ *     synchronises, allocates or frees (hipGraph-capture safe).  The library keeps NO streams, events or device memory
+ *     of its own: the only process state is the thread-local error string, the environment knobs read once
+ *     (sglk_reload_env) and per-device caches of two device properties (CU count, "dynamic LDS size raised" bits);
+ *   - calls act on the CURRENT device: make the device that owns `stream` and the buffers current before calling;
  *   - return value: 0 on success, negative SGLK_ERR_* otherwise; sglk_last_error() gives a thread-local
  *     message.  Shape/divisibility violations are rejected before anything is launched;
  *   - bf16 = uint16_t bit pattern, fp8 = OCP e4m3fn byte, strides in ELEMENTS.
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SGLK_VERSION 100 /* 0.1.0 */
+#define SGLK_VERSION 200 /* 0.2.0 */
 
 enum {
     SGLK_OK = 0,
@@ -56,6 +59,14 @@ int sglk_version(void);
 const char* sglk_last_error(void);
 /* number of compute units / name of device `dev` (host-side query used by the bench for roofline peaks) */
 int sglk_device_cu_count(int dev);
+/* Developer / test knobs (SGLK_* environment variables, listed in sgl-cpu-tests_amd/csrc/knobs.h) are read once, at
+ * first use.  This re-reads them; not thread-safe against concurrent calls into the library (tests call it between
+ * launches to switch tilings inside one process). */
+void sglk_reload_env(void);
+/* Convenience for callers that want sglk_fused_experts' optional second stream: creates a non-blocking stream and two
+ * timing-disabled events on the current device / destroys them.  The caller owns them; the library keeps no reference. */
+int sglk_aux_create(void** stream /* host out */, void** event0 /* host out */, void** event1 /* host out */);
+void sglk_aux_destroy(void* stream, void* event0, void* event1);
 
 /* ---------------------------------------------------------------------------------------------------------
  * convert_weight_packed        replaces torch.ops.sgl_kernel.convert_weight_packed
@@ -107,10 +118,47 @@ typedef struct {
     void* workspace;
     size_t workspace_bytes;
     void* stage_timer; /* optional sglk_stage_timer (NULL = off): records HIP events around every stage */
+    /* Optional second stream (hipStream_t) + two events (hipEvent_t, timing disabled) of the caller: when all three are
+     * given, the short tail tiles of a mid-size batch run on `aux_stream`, forked after the routing sort and joined before
+     * the combine (both inside this call, hipGraph-capture safe).  NULL: everything runs on `stream`. */
+    void* aux_stream;
+    void* aux_events[2];
+    int32_t flags;          /* SGLK_MOE_* bits */
+    int32_t* path_taken;    /* optional host out: which kernels this call used (SGLK_PATH_*), for measurement reports */
 } sglk_fused_experts_args;
 
+/* flags */
+enum {
+    /* opt-in "a8" mode of the fp8 path (NOT the reference's W8A16 numerics; never a default): activations are quantised
+     * per token x 128-wide block to e4m3 with a power-of-two scale and both GEMMs run on the block-scaled fp8 matrix
+     * cores (v_mfma_scale_f32_32x32x64_f8f6f4).  Needs packed weights, block [128k,128], K % 256 == 0, N % 128 == 0.
+     * Stated tolerance: DESIGN.md "a8 mode". */
+    SGLK_MOE_FP8_ACT = 1
+};
+/* path_taken: tile height of the grouped GEMMs (32 / 96 / 128 / 256; 64 = generic engine) | flag bits */
+enum {
+    SGLK_PATH_TILE_MASK = 0x3ff,
+    SGLK_PATH_FP8_ACT = 0x1000,       /* a8 kernels (moe_gemm_a8.hip) */
+    SGLK_PATH_TAILS_SPLIT = 0x2000,   /* tail tiles on the mid kernel */
+    SGLK_PATH_TAILS_AUX = 0x4000,     /* ... on the caller's aux stream */
+    SGLK_PATH_PERSIST_G1 = 0x8000,    /* GEMM-1 launched persistent (one workgroup per CU, tile loop + tickets) */
+    SGLK_PATH_PERSIST_G2 = 0x10000    /* GEMM-2 launched persistent */
+};
+
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
+/* the same with the SGLK_MOE_* flags of the call (the a8 mode keeps quantised copies of the activations) */
+size_t sglk_fused_experts_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype,
+                                             int32_t flags);
 int sglk_fused_experts(const sglk_fused_experts_args* args, void* stream);
+
+/* First stage of the opt-in a8 mode (SGLK_MOE_FP8_ACT), exported so that it can be checked bit for bit on its own:
+ * x [rows][cols] bf16 -> q [rows][cols] e4m3 + scale [rows][scale_stride] E8M0 bytes, one per 128-wide block
+ * (cols % 128 == 0): power-of-two scale 2^(byte-127) = the smallest with amax / scale <= 448, round to nearest even.
+ * q is stored in the k order of the packed weight tile (inside every 64 group position 32h+q holds
+ * k = 16h + {q | 32+q-8 | 8+q-16 | 40+q-24}), the order sglk_fused_experts' a8 kernels read.  No reference counterpart
+ * (the reference's fp8 op keeps bf16 activations, /root/reference/bench_moe.py:113-130). */
+int sglk_quant_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale, int64_t scale_stride,
+                            int64_t rows, int32_t cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * shared_expert               replaces torch.ops.sgl_kernel.shared_expert_cpu

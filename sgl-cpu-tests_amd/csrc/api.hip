@@ -2,7 +2,11 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "sglk_common.h"
+#include <stdlib.h>
+
+#include <mutex>
+
+#include "knobs.h"
 
 namespace sglk {
 static thread_local char g_err[512] = "";
@@ -13,7 +17,73 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+Knobs g_knobs;
+std::once_flag g_knobs_once;
+
+int env_int(const char* name, int unset) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : unset;
+}
+bool env_set(const char* name) { return getenv(name) != nullptr; }
+
+void read_env() {
+    Knobs k;
+    k.moe_tile_m = env_int("SGLK_MOE_TILE_M", 0);
+    k.mid_lo = env_int("SGLK_MID_LO", 8);
+    k.mid_hi = env_int("SGLK_MID_HI", 72);
+    k.force_generic = env_set("SGLK_FORCE_GENERIC");
+    k.no_i8_mid = env_set("SGLK_NO_I8_MID");
+    k.no_bf16_mid = env_set("SGLK_NO_BF16_MID");
+    k.tail_split = env_int("SGLK_TAIL_SPLIT", -1);
+    k.mid_down2 = env_int("SGLK_MID_DOWN2", -1);
+    k.bf16_w4 = env_set("SGLK_BF16_W4");
+    k.align_3pass = env_set("SGLK_ALIGN_3PASS");
+    k.wide_n = env_set("SGLK_WIDE_N");
+    k.persist = env_int("SGLK_PERSIST", -1);
+    k.max_wgs = env_int("SGLK_MAX_WGS", 0);
+    k.attn_order = env_int("SGLK_ATTN_ORDER", -1);
+    k.fp8_act = env_int("SGLK_FP8_ACT", 0);
+    k.rescale_ablate = env_int("SGLK_RESCALE", 0);
+    if (const char* dp = getenv("SGLK_DBG_PTR")) k.dbg_ptr = strtoull(dp, nullptr, 16);
+    g_knobs = k;
+}
+}  // namespace
+
+const Knobs& knobs() {
+    std::call_once(g_knobs_once, read_env);
+    return g_knobs;
+}
+
+int device_cu_count() {
+    static std::atomic<int> cus[32];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+int ensure_dyn_lds(const void* func, int bytes, std::atomic<unsigned>& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "%s: hipGetDevice failed", what);
+    const unsigned bit = 1u << (dev & 31);
+    if (done.load(std::memory_order_acquire) & bit) return SGLK_OK;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "%s: cannot reserve %d bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+    done.fetch_or(bit, std::memory_order_release);
+    return SGLK_OK;
+}
 }  // namespace sglk
+
+extern "C" void sglk_reload_env(void) {
+    sglk::knobs();        // make sure the once-flag is spent, then overwrite
+    sglk::read_env();
+}
 
 extern "C" int sglk_version(void) { return SGLK_VERSION; }
 
@@ -26,4 +96,28 @@ extern "C" int sglk_device_cu_count(int dev) {
         return SGLK_ERR_INVALID;
     }
     return prop.multiProcessorCount;
+}
+
+extern "C" int sglk_aux_create(void** stream, void** event0, void** event1) {
+    using namespace sglk;
+    SGLK_REQUIRE(stream && event0 && event1, SGLK_ERR_INVALID, "aux_create: null pointer");
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
+        if (e0) hipEventDestroy(e0);
+        if (st) hipStreamDestroy(st);
+        SGLK_FAIL(SGLK_ERR_LAUNCH, "aux_create: cannot create a stream and two events");
+    }
+    *stream = st;
+    *event0 = e0;
+    *event1 = e1;
+    return SGLK_OK;
+}
+
+extern "C" void sglk_aux_destroy(void* stream, void* event0, void* event1) {
+    if (event0) hipEventDestroy((hipEvent_t)event0);
+    if (event1) hipEventDestroy((hipEvent_t)event1);
+    if (stream) hipStreamDestroy((hipStream_t)stream);
 }

@@ -19,7 +19,7 @@
 // k_buffer[..., :DV], /root/reference/test_mla.py:83) the K image is reused for V and K is read from HBM once.
 // fp32 softmax, bf16 P, fp32 accumulation; optional logit soft-cap.  Decode writes per-split (O/l, lse) into the
 // caller's attn_logits [B][HQ][splits][DV+1] and a merge kernel combines them.
-#include "sglk_common.h"
+#include "knobs.h"
 
 namespace sglk {
 namespace attn {
@@ -320,17 +320,9 @@ struct ExtendParams {
     int B, nqblk, n_cu, order;   // launch geometry (see the kernel's workgroup-id decomposition)
 };
 
-static int attn_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    return cus;
-}
-static int attn_order(int dflt) {
-    static const char* e = getenv("SGLK_ATTN_ORDER");   // A/B override: bit 0 = flip second wave, bit 1 = heads fastest
-    return e ? atoi(e) : dflt;
+static int attn_cus() { return device_cu_count(); }
+static int attn_order(int dflt) {   // A/B override: bit 0 = flip second wave, bit 1 = heads fastest
+    return knobs().attn_order >= 0 ? knobs().attn_order : dflt;
 }
 
 // FORM (compile time, so that the extend form pays nothing for the others): 0 = extend_attention_cpu (paged prefix +

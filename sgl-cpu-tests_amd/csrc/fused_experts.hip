@@ -1,5 +1,6 @@
 // fused_experts: the C-ABI entry point that chains align -> GEMM-1(+SiLU*mul) -> GEMM-2(*topk_w) -> combine.
 // Operator contract: /root/reference/bench_moe.py:113-130 (14-arg), /root/reference/test_moe.py:79-92 (13-arg).
+#include "knobs.h"
 #include "moe_internal.h"
 
 #include <stdlib.h>
@@ -28,34 +29,33 @@ struct Workspace {
 //                and half its waves on padding); GEMM-1 runs at 4.5-5.5 TB/s of weight stream
 //   >= 72 rows : 256-token tiles, 8-wave LDS-DMA ring kernel
 //   shapes these cannot take (K % 256, very large operands): 128-token tiles
-int pick_tile_m(int M, int N, int K, int E, int topk) {
-    const char* force = getenv("SGLK_MOE_TILE_M");
+int pick_tile_m(int M, int N, int K, int E, int topk, int block_n, int64_t hidden_stride) {
+    const Knobs& kn = knobs();
     const int64_t S = (int64_t)M * topk;
-    // the 256 kernel addresses its operands through 32-bit buffer offsets
-    const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && S * (int64_t)N * 2 < (1ll << 32) &&
-                       (int64_t)M * K * 2 < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32);
+    // the 256 kernel addresses its operands through 32-bit buffer offsets (the rows of `hidden` by their STRIDE, which a
+    // row-strided view makes larger than K) and walks the scale table in 32-row operand tiles
+    const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && block_n % 32 == 0 && S * (int64_t)N * 2 < (1ll << 32) &&
+                       (int64_t)M * hidden_stride * 2 < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32);
     // stream kernel: both reduction lengths (K for GEMM-1, N for GEMM-2) must be multiples of 256 (ring of 8 pieces)
     const bool ok_stream = (K % 256 == 0) && (N % 256 == 0) && (int64_t)kStreamTileM * K * 2 <= 150 * 1024 &&
                            (int64_t)kStreamTileM * N * 2 <= 150 * 1024;
     // mid kernel: reduction lengths in whole 128s, 2 .. 64 blocks (scale table), 128 ic1 / 128 output columns per workgroup
     const bool ok_mid = (K % 128 == 0) && (N % 128 == 0) && K >= 256 && N >= 256 && K <= 8192 && N <= 8192;
-    if (force) {
-        const int f = atoi(force);
+    if (kn.moe_tile_m > 0) {
+        const int f = kn.moe_tile_m;
         if (f == 256 && ok256) return 256;
         if (f == 32 && ok_stream) return kStreamTileM;
         if (f == kMidTileM && ok_mid) return kMidTileM;
         if (f == 128) return 128;
     }
-    static const char* lo_env = getenv("SGLK_MID_LO");   // A/B overrides of the two crossovers (average rows per expert)
-    static const char* hi_env = getenv("SGLK_MID_HI");
-    const int64_t lo = lo_env ? atoi(lo_env) : 8, hi = hi_env ? atoi(hi_env) : 72;
+    const int64_t lo = kn.mid_lo, hi = kn.mid_hi;   // A/B overrides of the two crossovers (average rows per expert)
     if (ok_stream && S < lo * E) return kStreamTileM;
     if (ok_mid && S < hi * E) return kMidTileM;
     if (ok_stream && !ok_mid && S < (int64_t)44 * E) return kStreamTileM;
     return ok256 ? 256 : kTileM;
 }
 
-Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
+Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype, int flags) {
     Workspace w{};
     const int64_t S = (int64_t)M * topk;
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, kStreamTileM);   // the smallest tile bounds the table size
@@ -75,6 +75,12 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     w.tickets = take(16 * sizeof(int));
     w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
+    if (wtype == SGLK_W_FP8_E4M3 && (flags & SGLK_MOE_FP8_ACT)) {   // a8 mode: e4m3 copies + one e8m0 scale per 128-wide block
+        w.xq = take((size_t)M * K);
+        w.xs = take((size_t)M * align_up(K / 128, 4));
+        w.ic1q = take((size_t)S * N);
+        w.ic1s = take((size_t)S * align_up(N / 128, 4));
+    }
     if (wtype == SGLK_W_INT8) {   // W8A8: dynamically quantised activations of both GEMMs
         w.xq = take((size_t)M * K);
         w.xs = take((size_t)M * sizeof(float));
@@ -85,36 +91,16 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype) {
     return w;
 }
 
-// Side stream of the tail-tile launches (per thread and device, created on first use, never destroyed): the tail tiles'
-// GEMM-1 -> GEMM-2 chain is independent of the full tiles' (it reads and writes its own rows of ic1 / ic2), so it runs beside
-// the two big launches and fills the CUs their last tiles leave idle; fork after moe_align, join before the combine.
-struct SideStream {
-    hipStream_t st = nullptr;
-    hipEvent_t ev[16] = {};
-    unsigned next = 0;
-    int state = 0;   // 0 = not tried, 1 = ready, -1 = unavailable
-};
-static SideStream* side_stream() {
-    static thread_local SideStream ctx[16];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream& c = ctx[dev];
-    if (c.state == 0) {
-        c.state = -1;
-        if (hipStreamCreateWithFlags(&c.st, hipStreamNonBlocking) == hipSuccess) {
-            bool ok = true;
-            for (auto& e : c.ev) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            if (ok) c.state = 1;
-        }
-    }
-    return c.state == 1 ? &c : nullptr;
-}
+// The tail tiles' GEMM-1 -> GEMM-2 chain is independent of the full tiles' (it reads and writes its own rows of ic1 / ic2),
+// so it can run beside the two big launches and fill the CUs their last tiles leave idle: fork after moe_align, join before
+// the combine.  The second stream and the two events are the CALLER's (args->aux_stream / aux_events, e.g. from
+// sglk_aux_create); the library creates and keeps nothing.
 
 // shapes / layouts the tuned fp8 kernels (moe_gemm_fp8w*.hip) accept; everything else runs on the generic engine
 bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
     return a->wtype == SGLK_W_FP8_E4M3 && (a->packed & 3) == 3 && a->N % 128 == 0 && a->K % 128 == 0 && a->block_k == 128 &&
            a->block_n > 0 && a->block_n % 16 == 0 && (a->hidden_stride % 8) == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
-           getenv("SGLK_FORCE_GENERIC") == nullptr;
+           !knobs().force_generic;
 }
 
 // int8 fused_experts on the int8 matrix cores (gemm_i8_256.hip): packed weights, both reduction lengths whole 64-deep
@@ -124,14 +110,14 @@ bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
 bool mid_int8_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
-           S < (int64_t)44 * a->E && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr;
+           S < (int64_t)44 * a->E && !knobs().force_generic && !knobs().no_i8_mid;
 }
 
 bool tuned_int8_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 256 &&
            S >= (int64_t)44 * a->E && (int64_t)a->M * a->K < (1ll << 32) && S * (int64_t)a->N < (1ll << 32) &&
-           (int64_t)2 * a->N * a->K < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+           (int64_t)2 * a->N * a->K < (1ll << 32) && !knobs().force_generic;
 }
 
 // bf16 fused_experts on the tuned bf16 kernel (gemm_bf16_256.hip): VNNI-2 packed weights, whole tiles, large M
@@ -141,7 +127,7 @@ bool mid_bf16_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
            S < (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
-           getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_BF16_MID") == nullptr;
+           !knobs().force_generic && !knobs().no_bf16_mid;
 }
 
 bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
@@ -149,7 +135,7 @@ bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
     return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 128 &&
            S >= (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
            (int64_t)a->M * a->hidden_stride * 2 < (1ll << 32) && S * (int64_t)a->N * 2 < (1ll << 32) &&
-           (int64_t)4 * a->N * a->K < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+           (int64_t)4 * a->N * a->K < (1ll << 32) && !knobs().force_generic;
 }
 
 }  // namespace
@@ -157,7 +143,13 @@ bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
 extern "C" size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
                                                      int32_t wtype) {
     if (M < 0 || N <= 0 || K <= 0 || E <= 0 || topk <= 0) return 0;
-    return plan_workspace(M, N, K, E, topk, wtype).total;
+    return plan_workspace(M, N, K, E, topk, wtype, 0).total;
+}
+
+extern "C" size_t sglk_fused_experts_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk,
+                                                        int32_t wtype, int32_t flags) {
+    if (M < 0 || N <= 0 || K <= 0 || E <= 0 || topk <= 0) return 0;
+    return plan_workspace(M, N, K, E, topk, wtype, flags).total;
 }
 
 extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream) {
@@ -193,7 +185,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     }
     SGLK_REQUIRE(((uintptr_t)a->out % 2) == 0 && ((uintptr_t)a->hidden % 2) == 0, SGLK_ERR_INVALID, "fused_experts: misaligned");
 
-    const Workspace w = plan_workspace(M, N, K, E, topk, a->wtype);
+    SGLK_REQUIRE((a->flags & ~SGLK_MOE_FP8_ACT) == 0, SGLK_ERR_INVALID, "fused_experts: unknown flags 0x%x", a->flags);
+    const Workspace w = plan_workspace(M, N, K, E, topk, a->wtype, a->flags);
     SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "fused_experts: workspace %zu < required %zu",
                  a->workspace_bytes, w.total);
     SGLK_REQUIRE(((uintptr_t)a->workspace % 256) == 0, SGLK_ERR_INVALID, "fused_experts: workspace must be 256-B aligned");
@@ -214,21 +207,32 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         if (tm) hipEventRecord(tm->at(call, i), s);
     };
     const bool tuned = tuned_fp8_ok(a);
+    const bool a8 = (a->flags & SGLK_MOE_FP8_ACT) != 0;
+    if (a8) {   // an explicit request: refuse what the a8 kernels cannot take instead of answering with other numerics
+        SGLK_REQUIRE(tuned && K % 256 == 0 && N % 128 == 0 && a->block_n % 32 == 0 && K <= 4096 && N <= 4096 &&
+                         (int64_t)M * K < (1ll << 32) && (int64_t)M * topk * N < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32),
+                     SGLK_ERR_SHAPE, "fused_experts: SGLK_MOE_FP8_ACT needs packed fp8 weights, block [32k,128], K %% 256 == 0, "
+                     "N %% 128 == 0, K,N <= 4096 (got N=%d K=%d block_n=%d packed=%d)", N, K, a->block_n, a->packed);
+    }
     const bool mid_i8 = mid_int8_ok(a);
     const bool tuned_i8 = !mid_i8 && tuned_int8_ok(a);
     const bool mid_b16 = mid_bf16_ok(a);
     const bool tuned_b16 = !mid_b16 && tuned_bf16_ok(a);
-    const int tile_m = tuned ? pick_tile_m(M, N, K, E, topk) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
+    const int tile_m = a8 ? 256 : tuned ? pick_tile_m(M, N, K, E, topk, a->block_n, a->hidden_stride) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
-    const char* tail_env = getenv("SGLK_TAIL_SPLIT");   // 0 = off, 1 = on the caller's stream, default = side stream
+    // SGLK_TAIL_SPLIT: 0 = off, 1 = on the caller's stream; unset = on the caller's aux stream when one is given, else off
+    // (on the caller's own stream the tails cost more than they save: 0.454 vs 0.440 ms at M = 4096, 0.402 beside)
+    const int tail_knob = knobs().tail_split;
+    const bool have_aux = a->aux_stream && a->aux_events[0] && a->aux_events[1];
     // Same-box A/B at Qwen3 dims (tools/ab_tail_split.sh): M = 3929 -1.8 %, 4096 -8 %, 8192 -0.7 %, but 16384 +1.5 % and
     // 32768 +1.7 % (few tails per full tile, and the side launches get in the big kernels' way) -> only below ~640 rows per
     // expert.
     const bool split_tails = tuned && tile_m == 256 && K % 256 == 0 && N % 256 == 0 && K <= 4096 && N <= 4096 &&
-                             (int64_t)M * topk < (int64_t)640 * E && !(tail_env && tail_env[0] == '0');
-    SideStream* side = (split_tails && !(tail_env && tail_env[0] == '1')) ? side_stream() : nullptr;
+                             (int64_t)M * topk < (int64_t)640 * E && !(a->flags & SGLK_MOE_FP8_ACT) &&
+                             (tail_knob == 1 || (tail_knob != 0 && have_aux));
+    const bool side = split_tails && tail_knob != 1 && have_aux;
     int* tile_info_b = (int*)(ws + w.tile_info_b);
     int* num_tiles_b = (int*)(ws + w.num_tiles_b);
     mark(0);
@@ -239,7 +243,67 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
-    if (tuned) {
+    if (a8) {
+        // quantise hidden (one pass), GEMM-1 + SiLU*mul + ic1 quantisation, GEMM-2 + routing weight (moe_gemm_a8.hip)
+        uint8_t* xq = ws + w.xq;
+        uint8_t* xs = ws + w.xs;
+        uint8_t* ic1q = ws + w.ic1q;
+        uint8_t* ic1s = ws + w.ic1s;
+        const int xs_stride = (int)align_up(K / 128, 4), ic1s_stride = (int)align_up(N / 128, 4);
+        rc = launch_quant_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, xs_stride, M, K, s);
+        if (rc != SGLK_OK) return rc;
+        mark(1);   // the quantisation pass counts towards the align stage
+        A8GemmParams q1{};
+        q1.x = xq;
+        q1.x_stride = K;
+        q1.x_bytes = (int64_t)M * K;
+        q1.xs = xs;
+        q1.xs_stride = xs_stride;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_expert_stride = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+        q1.scale_cols = K / 128;
+        q1.block_n = a->block_n;
+        q1.C = K;
+        q1.n_half = N;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.n_tiles = N / 128;
+        q1.out = ic1q;
+        q1.out_stride = N;
+        q1.out_s = ic1s;
+        q1.out_s_stride = ic1s_stride;
+        rc = launch_moe_gemm_a8(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        A8GemmParams q2{};
+        q2.x = ic1q;
+        q2.x_stride = N;
+        q2.x_bytes = (int64_t)M * topk * N;
+        q2.xs = ic1s;
+        q2.xs_stride = ic1s_stride;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_expert_stride = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = (int)ceil_div(K, a->block_n);
+        q2.scale_cols = N / 128;
+        q2.block_n = a->block_n;
+        q2.C = N;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.n_tiles = K / 256;
+        q2.out = ic2;
+        q2.out_stride = K;
+        q2.topk_weights = a->topk_weights;
+        rc = launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else if (tuned) {
         MoeGemmParams g1{};
         g1.x = (const uint16_t*)a->hidden;
         g1.x_stride = a->hidden_stride;
@@ -266,11 +330,8 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
             g1.tickets = tickets;
         }
 #ifdef SGLK_DEV_ABLATE
-        if (const char* dp = getenv("SGLK_DBG_PTR")) g1.dbg = (unsigned long long*)strtoull(dp, nullptr, 16);
+        if (knobs().dbg_ptr) g1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
-        // 256-token tiles: 32x32x16 MFMA kernel unless the scale blocks are finer than its 32-row operand tiles
-        static const bool force16 = getenv("SGLK_MFMA16") != nullptr;
-        const bool use32 = !force16 && a->block_n % 32 == 0;
         hipEvent_t ev_join = nullptr;
         if (split_tails) {
             const int tails_max = E < max_tiles ? E : max_tiles;
@@ -299,11 +360,11 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
             t2.topk_weights = a->topk_weights;
             hipStream_t ts = s;
             if (side) {   // fork: the side stream starts once moe_align (and the ticket reset) are done
-                hipEvent_t ev_fork = side->ev[side->next++ & 15];
-                ev_join = side->ev[side->next++ & 15];
-                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent(side->st, ev_fork, 0) != hipSuccess)
-                    SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream fork failed");
-                ts = side->st;
+                hipEvent_t ev_fork = (hipEvent_t)a->aux_events[0];
+                ev_join = (hipEvent_t)a->aux_events[1];
+                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent((hipStream_t)a->aux_stream, ev_fork, 0) != hipSuccess)
+                    SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream fork failed");
+                ts = (hipStream_t)a->aux_stream;
             }
             // with a side stream both tail launches go out here, before the big GEMM-1, and overlap it and GEMM-2; on the
             // caller's stream they simply run first
@@ -311,10 +372,9 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
             if (rc != SGLK_OK) return rc;
             rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
             if (rc != SGLK_OK) return rc;
-            if (side && hipEventRecord(ev_join, side->st) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream record failed");
+            if (side && hipEventRecord(ev_join, ts) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream record failed");
         }
-        rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_GATE_UP, g1, max_tiles, s)
-                                    : launch_moe_gemm_fp8w_256(MODE_GATE_UP, g1, max_tiles, s))
+        rc = tile_m == 256 ? launch_moe_gemm_fp8w_256i(MODE_GATE_UP, g1, max_tiles, s)
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_GATE_UP, g1, max_tiles, s)
              : tile_m == kMidTileM    ? launch_moe_gemm_fp8w_mid(MODE_GATE_UP, g1, max_tiles, s)
                                       : launch_moe_gemm_fp8w(MODE_GATE_UP, g1, max_tiles, s);
@@ -338,8 +398,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
         // mid kernel, DOWN: two 128-column tiles per workgroup on one weight ring when the shapes allow (SGLK_MID_DOWN2=0: one)
-        const char* d2_env = getenv("SGLK_MID_DOWN2");
-        const bool mid_down2 = tile_m == kMidTileM && N % 256 == 0 && K % 256 == 0 && !(d2_env && d2_env[0] == '0');
+        const bool mid_down2 = tile_m == kMidTileM && N % 256 == 0 && K % 256 == 0 && knobs().mid_down2 != 0;
         g2.n_tiles = (tile_m == 128 || (tile_m == kMidTileM && !mid_down2)) ? K / 128 : K / 256;
         g2.out = ic2;
         g2.out_stride = K;
@@ -348,8 +407,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
 #ifdef SGLK_DEV_ABLATE
         if (g1.dbg) g2.dbg = g1.dbg + 32 * 8192;
 #endif
-        rc = tile_m == 256 ? (use32 ? launch_moe_gemm_fp8w_256x(MODE_DOWN, g2, max_tiles, s)
-                                    : launch_moe_gemm_fp8w_256(MODE_DOWN, g2, max_tiles, s))
+        rc = tile_m == 256 ? launch_moe_gemm_fp8w_256i(MODE_DOWN, g2, max_tiles, s)
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)
              : tile_m == kMidTileM    ? (mid_down2 ? launch_moe_gemm_fp8w_mid_down2(g2, max_tiles, s)
                                                     : launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s))
@@ -633,6 +691,15 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
 
     rc = launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
     mark(4);
+    if (a->path_taken) {
+        int path = (tile_m & SGLK_PATH_TILE_MASK) | (a8 ? SGLK_PATH_FP8_ACT : 0);
+        if (split_tails) path |= SGLK_PATH_TAILS_SPLIT | (side ? SGLK_PATH_TAILS_AUX : 0);
+        if (tuned && !a8 && tile_m == 256) {
+            if (moe_gemm_fp8w_256i_is_persistent(K, (int64_t)max_tiles * (N / 128))) path |= SGLK_PATH_PERSIST_G1;
+            if (moe_gemm_fp8w_256i_is_persistent(N, (int64_t)max_tiles * (K / 256))) path |= SGLK_PATH_PERSIST_G2;
+        }
+        *a->path_taken = path;
+    }
     return rc;
 }
 
@@ -679,4 +746,13 @@ extern "C" int sglk_stage_timer_read(void* timer, float* mean_ms, int32_t* calls
         }
     for (int i = 0; i < SGLK_NUM_STAGES; ++i) mean_ms[i] /= (float)t->calls;
     return SGLK_OK;
+}
+
+extern "C" int sglk_quant_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale,
+                                       int64_t scale_stride, int64_t rows, int32_t cols, void* stream) {
+    SGLK_REQUIRE(rows >= 0 && cols > 0, SGLK_ERR_INVALID, "quant_fp8_block128: bad sizes");
+    SGLK_REQUIRE(rows == 0 || (x && q && scale), SGLK_ERR_INVALID, "quant_fp8_block128: null pointer");
+    SGLK_REQUIRE(x_stride >= cols && q_stride >= cols && scale_stride >= cols / 128, SGLK_ERR_INVALID, "quant_fp8_block128: stride");
+    return launch_quant_fp8_block128((const uint16_t*)x, x_stride, (uint8_t*)q, q_stride, (uint8_t*)scale, scale_stride, rows, cols,
+                                     (hipStream_t)stream);
 }

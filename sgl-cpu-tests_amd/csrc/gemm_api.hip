@@ -1,6 +1,7 @@
 // Dense entry points of the C-ABI built on the generic engine: shared_expert, scaled_mm (fp8 / int8 / bf16 weights).
 #include <stdlib.h>
 
+#include "knobs.h"
 #include "moe_internal.h"
 
 using namespace sglk;
@@ -11,11 +12,11 @@ struct DenseWs {
     size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, partial, total;
 };
 
-// the tuned 256-token fp8 kernel (moe_gemm_fp8w_256x.hip) takes a dense [M][C] x [R][C]^T when this holds
+// the tuned 256-token fp8 kernel (moe_gemm_fp8w_256i.hip) takes a dense [M][C] x [R][C]^T when this holds
 bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int block_k, const void* x, int64_t x_stride) {
-    return wtype == SGLK_W_FP8_E4M3 && packed && M >= 192 && R % 256 == 0 && C % 128 == 0 && (C >> 7) <= 64 &&
+    return wtype == SGLK_W_FP8_E4M3 && packed && M >= 192 && R % 256 == 0 && C % 128 == 0 && C >= 256 && (C >> 7) <= 64 &&
            block_k == 128 && block_n % 32 == 0 && x_stride % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
-           (int64_t)M * x_stride * 2 < (1ll << 32) && (int64_t)R * C < (1ll << 32) && getenv("SGLK_FORCE_GENERIC") == nullptr;
+           (int64_t)M * x_stride * 2 < (1ll << 32) && (int64_t)R * C < (1ll << 32) && !knobs().force_generic;
 }
 
 void fill_tuned(MoeGemmParams& g, const void* x, int64_t x_stride, int M, const int* ident, const void* w,
@@ -165,7 +166,7 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
         t1.n_tiles = N / 128;
         t1.out = ic1;
         t1.out_stride = N;
-        rc = launch_moe_gemm_fp8w_256x(MODE_GATE_UP, t1, t256, s);
+        rc = launch_moe_gemm_fp8w_256i(MODE_GATE_UP, t1, t256, s);
         if (rc != SGLK_OK) return rc;
         MoeGemmParams t2{};
         fill_tuned(t2, ic1, N, M, ident, a->w2, a->w2_scale, K, N, a->block_n, tile_info, num_tiles);
@@ -175,13 +176,13 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
         t2.addend = (const uint16_t*)a->fused_out;
         t2.addend_stride = a->fused_out_stride;
         t2.addend_scale = a->routed_scaling_factor;
-        return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t2, t256, s);
+        return launch_moe_gemm_fp8w_256i(MODE_PLAIN, t2, t256, s);
     }
     // fp8, decode-size M: both GEMMs as split-K passes of the weight-streaming kernel; the gate_up partials are reduced by a
     // SiLU*mul pass (fp32 until the single bf16 rounding of ic1, like the fused path), the down partials by the ordered reduce
     // that also adds fused_out * routed_scaling_factor
     if (a->wtype == SGLK_W_FP8_E4M3 && (a->packed & 3) == 3 && a->block_k == 128 && a->block_n > 0 && a->block_n % 16 == 0 &&
-        a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 && !knobs().force_generic) {
         const int k1 = mid_dense_ksplit(M, 2 * N, K), k2 = mid_dense_ksplit(M, K, N);
         if (k1 >= 1 && k2 >= 1) {
             float* partial = (float*)(ws + w.partial);
@@ -224,7 +225,7 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
     }
     // int8 W8A8, decode sizes (M <= 128): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
     // (fp32 ic1), quantise ic1, down as int32 partials, reduce with the scales + fused_out * routed_scaling_factor
-    if (i8 && (a->packed & 3) == 3 && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr) {
+    if (i8 && (a->packed & 3) == 3 && !knobs().force_generic && !knobs().no_i8_mid) {
         const int k1 = i8_mid_ksplit(M, 2 * N, K), k2 = i8_mid_ksplit(M, K, N);
         if (k1 >= 1 && k2 >= 1) {
             int32_t* partial = (int32_t*)(ws + w.partial);
@@ -272,7 +273,7 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
     }
     // bf16 packed weights, decode sizes: the same four launches on the bf16 weight-streaming kernel
     if (a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
-        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        !knobs().force_generic) {
         const int k1 = bf16_mid_ksplit(M, 2 * N, K), k2 = bf16_mid_ksplit(M, K, N);
         if (k1 >= 1 && k2 >= 1) {
             float* partial = (float*)(ws + w.partial);
@@ -412,12 +413,12 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         t.out = (uint16_t*)a->out;
         t.out_stride = a->out_stride;
         t.bias = a->bias;
-        return launch_moe_gemm_fp8w_256x(MODE_PLAIN, t, t256, s);
+        return launch_moe_gemm_fp8w_256i(MODE_PLAIN, t, t256, s);
     }
     // fp8, decode-size M: weight-streaming mid kernel (one "expert"), K cut into ranges until ~2 workgroups per CU exist
     if (a->wtype == SGLK_W_FP8_E4M3 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->block_k == 128 &&
         a->block_n > 0 && a->block_n % 16 == 0 && a->x_stride % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 &&
-        ((uintptr_t)a->out % 8) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0) && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        ((uintptr_t)a->out % 8) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0) && !knobs().force_generic) {
         const int ks = mid_dense_ksplit(M, N, K);
         if (ks >= 1) {
             const int mt = (int)ceil_div(M, kMidTileM);
@@ -449,7 +450,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     // bf16 packed weights, decode-size M: the same weight-streaming scheme without a conversion (gemm_bf16_mid.hip)
     if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->x_stride % 8 == 0 &&
         ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 && ((uintptr_t)a->out % 8) == 0 &&
-        (!a->bias || ((uintptr_t)a->bias % 16) == 0) && ((uintptr_t)a->w % 4) == 0 && getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        (!a->bias || ((uintptr_t)a->bias % 16) == 0) && ((uintptr_t)a->w % 4) == 0 && !knobs().force_generic) {
         const int ks = bf16_mid_ksplit(M, N, K);
         if (ks >= 1) {
             BmidParams q{};
@@ -481,7 +482,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && M >= 192 && N % 256 == 0 && K % 32 == 0 && K >= 128 &&
         a->out_type == SGLK_OUT_BF16 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && a->x_stride % 8 == 0 &&
         ((uintptr_t)a->x % 16) == 0 && (int64_t)M * a->x_stride * 2 < (1ll << 32) && (int64_t)N * K * 2 < (1ll << 32) &&
-        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        !knobs().force_generic) {
         Bf16GemmParams q{};
         q.x = (const uint16_t*)a->x;
         q.x_stride = a->x_stride * 2;
@@ -497,7 +498,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
     }
     // W8A8 at decode sizes (M <= 128): weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)
-    if (a->wtype == SGLK_W_INT8 && a->packed && getenv("SGLK_FORCE_GENERIC") == nullptr && getenv("SGLK_NO_I8_MID") == nullptr) {
+    if (a->wtype == SGLK_W_INT8 && a->packed && !knobs().force_generic && !knobs().no_i8_mid) {
         const int ks = i8_mid_ksplit(M, N, K);
         if (ks >= 1) {
             const int8_t* xq = (const int8_t*)a->x;
@@ -537,7 +538,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     // W8A8 on the int8 matrix cores (exact int32 accumulation): packed int8 weights, large M
     if (a->wtype == SGLK_W_INT8 && a->packed && M >= 192 && N % 256 == 0 && K % 64 == 0 && K >= 256 && a->out_type == SGLK_OUT_BF16 &&
         a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && (int64_t)N * K < (1ll << 32) &&
-        getenv("SGLK_FORCE_GENERIC") == nullptr) {
+        !knobs().force_generic) {
         const int8_t* xq = (const int8_t*)a->x;
         int64_t xq_stride = a->x_stride;
         const float* xs = a->x_scale;

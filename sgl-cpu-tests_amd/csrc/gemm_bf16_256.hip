@@ -15,7 +15,7 @@
 // fp32 accumulation, one rounding to bf16 (GATE_UP: after SiLU*mul; DOWN: after the routing weight).
 #include <stdlib.h>
 
-#include "sglk_common.h"
+#include "knobs.h"
 #include "moe_internal.h"
 
 namespace sglk {
@@ -518,7 +518,7 @@ int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipS
     if (p.K < 128 || p.K % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_256: reduction length %d must be a multiple of 32 and >= 128", p.K);
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks <= 0) return SGLK_OK;
-    static const bool w4 = getenv("SGLK_BF16_W4") != nullptr;
+    const bool w4 = knobs().bf16_w4;
     if (w4 && mode == MODE_PLAIN && !p.tile_info) {
         hipLaunchKernelGGL(gb16::gemm_bf16_256w4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
         SGLK_CHECK_LAUNCH("gemm_bf16_256w4");

@@ -13,7 +13,7 @@
 //   counted s_waitcnt + one barrier per block -- waits are builtins so that the compiler's own wait-count pass sees them;
 // * the reduction is cut into equal ranges of an even number (>= 4) of K blocks until ~512 workgroups exist; fp32 partials
 //   [range][row][N] are summed in range order by the generic engine's reduce (bias and the bf16 rounding happen there).
-#include "sglk_common.h"
+#include "knobs.h"
 #include "moe_internal.h"
 
 namespace sglk {
@@ -260,12 +260,8 @@ int launch_gemm_bf16_mid(const BmidParams& p, hipStream_t stream) {
     const bool odd = (kblocks & 1) != 0;
 #define BMID_PLAIN(TMV, OD)                                                                                        \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
         const size_t lds = 2 * TMV * 256 + 2 * TMV * 4;                                                            \
-        if (!attr) {                                                                                               \
-            hipFuncSetAttribute((const void*)gbmid::gemm_bf16_mid_kernel<MODE_PLAIN, TMV, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        SGLK_ENSURE_DYN_LDS((gbmid::gemm_bf16_mid_kernel<MODE_PLAIN, TMV, OD>), lds, "gemm_bf16_mid");             \
         hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_PLAIN, TMV, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
     }
     if (tm == 64) { if (odd) BMID_PLAIN(64, true) else BMID_PLAIN(64, false) }

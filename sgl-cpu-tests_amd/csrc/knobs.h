@@ -1,0 +1,46 @@
+// Developer / test knobs of the library, read from the environment ONCE (first use) and cached; sglk_reload_env()
+// (include/sglk.h) re-reads them, which is how the parity tests switch paths inside one process.  None of them changes a
+// result beyond the stated tolerances; the defaults are what ships.
+#pragma once
+#include <atomic>
+
+#include "sglk_common.h"
+
+namespace sglk {
+
+struct Knobs {
+    int moe_tile_m = 0;          // SGLK_MOE_TILE_M: force the fp8 grouped-GEMM tiling (32 / 96 / 128 / 256); 0 = by batch size
+    int mid_lo = 8, mid_hi = 72; // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256
+    bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
+    bool no_i8_mid = false;      // SGLK_NO_I8_MID
+    bool no_bf16_mid = false;    // SGLK_NO_BF16_MID
+    int tail_split = -1;         // SGLK_TAIL_SPLIT: 0 = off, 1 = on the caller's stream, unset = caller's aux stream if given
+    int mid_down2 = -1;          // SGLK_MID_DOWN2: 0 = one column tile per workgroup
+    bool bf16_w4 = false;        // SGLK_BF16_W4: four-wave form of the bf16 256-row kernel
+    bool align_3pass = false;    // SGLK_ALIGN_3PASS: moe_align always as count / scan / scatter
+    bool wide_n = false;         // SGLK_WIDE_N: wave layout 2(n) x 4(m) of the fp8 256-row kernel
+    int persist = -1;            // SGLK_PERSIST: 0 = one workgroup per tile, 1 = persistent; unset = by reduction length
+    int max_wgs = 0;             // SGLK_MAX_WGS: cap on the persistent launches' workgroups (tests: forces many tiles per
+                                 //               workgroup on small problems); 0 = one per CU
+    int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
+    int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)
+    int rescale_ablate = 0;      // SGLK_RESCALE (SGLK_DEV_ABLATE builds only)
+    unsigned long long dbg_ptr = 0;   // SGLK_DBG_PTR (SGLK_DEV_ABLATE builds only)
+};
+
+const Knobs& knobs();
+
+// compute units of the CURRENT device (cached per device)
+int device_cu_count();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device); `done` is the call site's bit mask
+int ensure_dyn_lds(const void* func, int bytes, std::atomic<unsigned>& done, const char* what);
+
+#define SGLK_ENSURE_DYN_LDS(func, bytes, what)                                            \
+    do {                                                                                  \
+        static std::atomic<unsigned> done_{0};                                            \
+        const int rc_ = ::sglk::ensure_dyn_lds((const void*)(func), (int)(bytes), done_, what); \
+        if (rc_ != SGLK_OK) return rc_;                                                   \
+    } while (0)
+
+}  // namespace sglk

@@ -13,7 +13,7 @@
 //   scatter : one wave per chunk, rank inside the wave by ballot match, running LDS counters across rounds
 #include <stdlib.h>
 
-#include "sglk_common.h"
+#include "knobs.h"
 
 namespace sglk {
 
@@ -288,7 +288,7 @@ int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_
     int nbits = 0;
     while ((1 << nbits) < E) ++nbits;
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
-    if (tail_max <= 0 && S <= kSmallSlots && E <= kSmallMaxE && getenv("SGLK_ALIGN_3PASS") == nullptr) {
+    if (tail_max <= 0 && S <= kSmallSlots && E <= kSmallMaxE && !knobs().align_3pass) {
         hipLaunchKernelGGL(moe_align_small_kernel, dim3(1), dim3(1024), 0, s, topk_ids, S, E, nbits, tile_m, max_tiles,
                            sorted_slot, expert_off, tile_info, num_tiles);
         SGLK_CHECK_LAUNCH("moe_align");

@@ -20,7 +20,7 @@
 //     stored with 16-byte accesses (ic1 rows are contiguous positions, ic2 rows are scattered by slot).
 #include <stdlib.h>
 
-#include "sglk_common.h"
+#include "knobs.h"
 #include "moe_internal.h"
 
 namespace sglk {
@@ -107,10 +107,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #endif
     int xs, xl, nbx;
     {
-        const int x = blockIdx.x & 7, q = live >> 3, r = live & 7;
+        // a launch of fewer than 8 workgroups (grid-cap knob of the tests) cuts the tiles into that many ranges instead
+        const int np = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+        const int x = np == 8 ? (int)(blockIdx.x & 7) : (int)blockIdx.x, q = live / np, r = live - q * np;
         xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
         xl = q + (x < r ? 1 : 0);
-        nbx = ((int)gridDim.x - x + 7) >> 3;   // workgroups of this launch on XCD x
+        nbx = ((int)gridDim.x - x + np - 1) / np;   // workgroups of this launch on XCD x
     }
     // Tile sequence of the workgroup inside its XCD's range: four static rounds (j0 + k * nbx), then tickets from a
     // per-XCD counter (p.tickets, zeroed by the caller) -- a workgroup that drew cheap tail tiles simply draws again, like
@@ -668,27 +670,39 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 
 }  // namespace g256i
 
+// Persistent launch (one workgroup per CU walking a strided share of the tiles, next tile's tables prefetched) vs one
+// workgroup per tile (hardware dispatch balances tail tiles better).  Returns the grid size; *persistent says which.
+static int64_t plan_grid_256i(int C, int64_t tiles, bool* persistent) {
+    const Knobs& kn = knobs();
+    int cus = device_cu_count();
+    const bool persist = kn.persist >= 0 ? kn.persist == 1 : C <= 1024;   // SGLK_PERSIST: A/B and test override
+    if (persist && kn.max_wgs > 0 && kn.max_wgs < cus) cus = kn.max_wgs;   // SGLK_MAX_WGS: many tiles per workgroup on small problems
+    const bool p = persist && tiles > cus;
+    if (persistent) *persistent = p;
+    return p ? cus : tiles;
+}
+bool moe_gemm_fp8w_256i_is_persistent(int C, int64_t tiles) {
+    bool p = false;
+    plan_grid_256i(C, tiles, &p);
+    return p;
+}
+
 int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream) {
     int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    // Persistent launch (one workgroup per CU walking a strided share of the tiles, next tile's tables prefetched) vs one
-    // workgroup per tile (hardware dispatch balances tail tiles better).  Measured A/B on one box at the bench shape:
-    // persistent wins for the short reduction (K = 768: 0.464 vs 0.468 ms), loses for the long one (K = 2048: 0.778 vs
-    // 0.765 ms) where the prologue is a smaller share and the static split's imbalance costs more.
-    static const char* force = getenv("SGLK_PERSIST");   // "0" / "1" override for A/B runs
-    const bool persist = force ? force[0] == '1' : p.C <= 1024;
-    if (blocks > cus && persist) blocks = cus;
-    static const bool wide_n = getenv("SGLK_WIDE_N") != nullptr;   // wave layout 2(n) x 4(m) instead of 4(n) x 2(m)
-    if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256x: reduction length %d too long", p.C);
+    // Measured A/B on one box at the bench shape: persistent wins for the short reduction (K = 768: 0.464 vs 0.468 ms),
+    // loses for the long one (K = 2048: 0.778 vs 0.765 ms) where the prologue is a smaller share and the static split's
+    // imbalance costs more.
+    const Knobs& kn = knobs();
+    blocks = plan_grid_256i(p.C, blocks, nullptr);
+    const bool wide_n = kn.wide_n;   // wave layout 2(n) x 4(m) instead of 4(n) x 2(m)
+    if ((p.C >> 7) > g256i::kMaxKBlocks) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256i: reduction length %d too long", p.C);
+    if ((p.C >> 7) < 2 || p.C % 128 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256i: reduction length %d needs at least two whole 128-wide K blocks", p.C);
+    if (p.block_n % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_256i: block_n %d is not a multiple of 32", p.block_n);
     if (mode == MODE_PLAIN) {
         if (wide_n) hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0, 4>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_PLAIN, 0, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p);
-        SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256x");
+        SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256i");
         return SGLK_OK;
     }
 #define SGLK_LAUNCH256X(R)                                                                                             \
@@ -701,7 +715,7 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
     else                                                                                                               \
         hipLaunchKernelGGL((g256i::moe_gemm_fp8w_256i_kernel<MODE_DOWN, R, 2>), dim3((unsigned)blocks), dim3(512), 0, stream, p)
 #ifdef SGLK_DEV_ABLATE   // developer-only timing ablations (wrong results by design)
-    static const int abl = getenv("SGLK_RESCALE") ? atoi(getenv("SGLK_RESCALE")) : 0;
+    const int abl = kn.rescale_ablate;
     switch (abl) {
         case 4: SGLK_LAUNCH256X(4); break;
         case 8: SGLK_LAUNCH256X(8); break;
@@ -717,7 +731,7 @@ int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, 
     SGLK_LAUNCH256X(0);
 #endif
 #undef SGLK_LAUNCH256X
-    SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256x");
+    SGLK_CHECK_LAUNCH("moe_gemm_fp8w_256i");
     return SGLK_OK;
 }
 

@@ -19,7 +19,7 @@
 //   weight tiles (8 MFMAs per 4 ds_read_b128);
 // * fp8 -> bf16 exactly (v_cvt_scalef32_pk_bf16_fp8, scale 1.0); the 128-block partial sum lives in a temporary and
 //   is folded into the accumulator with the block scale in fp32.
-#include "sglk_common.h"
+#include "knobs.h"
 #include "moe_internal.h"
 
 namespace sglk {
@@ -459,11 +459,7 @@ int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipSt
     if (p.C % 256 != 0 || kblocks < 2 || kblocks > gmid::kMaxKB) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid_down2: reduction length %d", p.C);
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_down2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gmid::kLds);
-        attr = true;
-    }
+    SGLK_ENSURE_DYN_LDS(gmid::moe_gemm_fp8w_mid_down2_kernel, gmid::kLds, "moe_gemm_fp8w_mid_down2");
     hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_down2_kernel, dim3((unsigned)blocks), dim3(512), gmid::kLds, stream, p);
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid_down2");
     return SGLK_OK;
@@ -481,11 +477,7 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
     const size_t lds = gmid::kLds;
 #define MID_LAUNCH2(MD, OD)                                                                                        \
     {                                                                                                              \
-        static bool attr = false;                                                                                  \
-        if (!attr) {                                                                                               \
-            hipFuncSetAttribute((const void*)gmid::moe_gemm_fp8w_mid_kernel<MD, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr = true;                                                                                           \
-        }                                                                                                          \
+        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MD, OD>), lds, "moe_gemm_fp8w_mid");                   \
         hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
     }
 #define MID_LAUNCH(MD)                                                                                             \

@@ -13,7 +13,7 @@
 //   kDepth pieces in flight (statically indexed registers), issued before the activation tile is even loaded, so
 //   the stream never waits on a barrier: 8 waves x kDepth KiB per CU in flight;
 // * fp8 -> bf16 exactly (v_cvt_scalef32_pk_bf16_fp8, scale 1.0), per-128-K-block partial accumulator scaled in fp32.
-#include "sglk_common.h"
+#include "knobs.h"
 #include "moe_internal.h"
 
 namespace sglk {
@@ -177,20 +177,10 @@ int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles
     const size_t lds = (size_t)kStreamTileM * p.C * 2;
     if (lds > 150 * 1024) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_stream: reduction length %d too long for the LDS tile", p.C);
     if (mode == MODE_GATE_UP) {
-        static bool attr1 = false;
-        if (!attr1) {
-            hipFuncSetAttribute((const void*)gstream::moe_gemm_fp8w_stream_kernel<MODE_GATE_UP>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr1 = true;
-        }
+        SGLK_ENSURE_DYN_LDS(gstream::moe_gemm_fp8w_stream_kernel<MODE_GATE_UP>, 150 * 1024, "moe_gemm_fp8w_stream");
         hipLaunchKernelGGL(gstream::moe_gemm_fp8w_stream_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
     } else {
-        static bool attr2 = false;
-        if (!attr2) {
-            hipFuncSetAttribute((const void*)gstream::moe_gemm_fp8w_stream_kernel<MODE_DOWN>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            attr2 = true;
-        }
+        SGLK_ENSURE_DYN_LDS(gstream::moe_gemm_fp8w_stream_kernel<MODE_DOWN>, 150 * 1024, "moe_gemm_fp8w_stream");
         hipLaunchKernelGGL(gstream::moe_gemm_fp8w_stream_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
     }
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_stream");

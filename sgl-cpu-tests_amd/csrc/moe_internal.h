@@ -43,13 +43,40 @@ struct MoeGemmParams {
 };
 
 int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
-// 256-token x 256-row tiles, 8 waves, 3-deep LDS-DMA ring (moe_gemm_fp8w_256.hip); tile table built with tile_m = 256
-int launch_moe_gemm_fp8w_256(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
-// same tiling on mfma_f32_32x32x16_bf16 (moe_gemm_fp8w_256x.hip); needs block_n % 32 == 0
-int launch_moe_gemm_fp8w_256x(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
-// same tile and ring, main loop issued MFMA by MFMA with the next k-step's feed in the shadows (moe_gemm_fp8w_256i.hip);
-// the 256x entry point forwards here unless SGLK_G256X is set
+// 256-token x 256-row tiles, 8 waves, 3-deep LDS-DMA ring on mfma_f32_32x32x16_bf16, main loop issued MFMA by MFMA with
+// the next k-step's feed in the shadows (moe_gemm_fp8w_256i.hip); tile table built with tile_m = 256; needs
+// block_n % 32 == 0 and a reduction of at least two 128-wide K blocks
 int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
+bool moe_gemm_fp8w_256i_is_persistent(int C, int64_t tiles);   // what that launch does for `tiles` workgroup tiles
+
+// ---- opt-in a8 mode: fp8 activations x fp8 weights on the block-scaled fp8 matrix cores (moe_gemm_a8.hip) -----------------
+struct A8GemmParams {
+    const uint8_t* x;             // quantised activations: e4m3, packed-tile k order inside every 64 group
+    int64_t x_stride;             // bytes per row
+    int64_t x_bytes;              // extent (< 4 GiB, buffer descriptor)
+    const uint8_t* xs;            // E8M0 scale bytes [row][C / 128], row stride xs_stride (multiple of 4)
+    int xs_stride;
+    const int* sorted_slot;
+    int topk;
+    const uint8_t* w;             // packed fp8 weights [E][R][C]
+    int64_t w_expert_stride;
+    const float* w_scale;         // [E][scale_rows][scale_cols]
+    int scale_rows, scale_cols, block_n;
+    int C;                        // reduction length
+    int n_half;                   // GATE_UP: N
+    const int4* tile_info;        // tile_m = 256
+    const int* num_tiles;
+    int n_tiles;                  // GATE_UP: N / 128; DOWN: K / 256
+    void* out;                    // GATE_UP: ic1 e4m3 [position][N] (same k order); DOWN: ic2 bf16 [slot][K]
+    int64_t out_stride;           // GATE_UP: bytes per row; DOWN: elements per row
+    uint8_t* out_s;               // GATE_UP: ic1 scale bytes [position][out_s_stride]
+    int out_s_stride;
+    const float* topk_weights;    // DOWN
+};
+int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+// hidden bf16 [rows][cols] -> e4m3 (packed-tile k order) + one E8M0 byte per 128-wide block
+int launch_quant_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
+                              int64_t rows, int cols, hipStream_t stream);
 
 // ---- dense W8A8 GEMM on the int8 matrix cores (gemm_i8_256.hip) ----------------------------------------------------------
 struct I8GemmParams {

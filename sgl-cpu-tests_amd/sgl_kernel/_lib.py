@@ -6,6 +6,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SGLK_LIB_PATH") or os.path.join(_HERE, "libsglk.so")   # override: developer A/B builds
 
 W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2
+MOE_FP8_ACT = 1                      # sglk_fused_experts_args.flags
+PATH_TILE_MASK, PATH_FP8_ACT, PATH_TAILS_SPLIT, PATH_TAILS_AUX, PATH_PERSIST_G1, PATH_PERSIST_G2 = (
+    0x3ff, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000)
 
 
 class FusedExpertsArgs(ctypes.Structure):
@@ -21,6 +24,8 @@ class FusedExpertsArgs(ctypes.Structure):
         ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
         ("stage_timer", ctypes.c_void_p),
+        ("aux_stream", ctypes.c_void_p), ("aux_events", ctypes.c_void_p * 2),
+        ("flags", ctypes.c_int32), ("path_taken", ctypes.POINTER(ctypes.c_int32)),
     ]
 
 
@@ -104,12 +109,18 @@ _SIGNATURES = {
     "sglk_version": (ctypes.c_int, []),
     "sglk_last_error": (ctypes.c_char_p, []),
     "sglk_device_cu_count": (ctypes.c_int, [ctypes.c_int]),
+    "sglk_reload_env": (None, []),
+    "sglk_aux_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)] * 3),
+    "sglk_aux_destroy": (None, [ctypes.c_void_p] * 3),
     "sglk_pack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "sglk_unpack_weight": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                            ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "sglk_fused_experts_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 6),
+    "sglk_fused_experts_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int32] * 7),
     "sglk_fused_experts": (ctypes.c_int, [ctypes.POINTER(FusedExpertsArgs), ctypes.c_void_p]),
+    "sglk_quant_fp8_block128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_moe_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),
     "sglk_moe_max_tiles": (ctypes.c_int32, [ctypes.c_int32] * 4),
     "sglk_moe_align": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -1,5 +1,6 @@
 """torch.library registration of the sgl_kernel operators (reference signatures) over the sglk C-ABI."""
 import ctypes
+import os
 
 import torch
 
@@ -23,7 +24,13 @@ _ws_cache = {}
 
 def _workspace(nbytes, device):
     """Scratch for one call.  Reused per (device, stream): work on one stream is ordered, so the next call on the same
-    stream may overwrite it; other streams get their own buffer.  Grows monotonically."""
+    stream may overwrite it; other streams get their own buffer.  Grows monotonically.
+
+    Under hipGraph capture every call gets a FRESH buffer that is not cached: its address is baked into the graph, its
+    lifetime is the graph's private pool, and two graphs captured on one stream (which may be replayed concurrently on
+    different streams) must not share scratch -- nor may a later eager call's larger request drop a buffer a graph uses."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -32,6 +39,36 @@ def _workspace(nbytes, device):
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
+
+
+class _Aux:
+    """A second HIP stream + two events owned by this layer (sglk_aux_create), handed to sglk_fused_experts so that the
+    tail tiles of a mid-size batch run beside the big launches.  One per (device, caller stream)."""
+    __slots__ = ("stream", "ev0", "ev1")
+
+    def __init__(self):
+        st, e0, e1 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(_lib.lib().sglk_aux_create(ctypes.byref(st), ctypes.byref(e0), ctypes.byref(e1)), "aux_create")
+        self.stream, self.ev0, self.ev1 = st.value, e0.value, e1.value
+
+    def __del__(self):
+        try:
+            _lib.lib().sglk_aux_destroy(self.stream, self.ev0, self.ev1)
+        except Exception:
+            pass
+
+
+_aux_cache = {}
+
+
+def _aux(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    a = _aux_cache.get(key)
+    if a is None:
+        if len(_aux_cache) > 64:
+            _aux_cache.clear()
+        a = _aux_cache[key] = _Aux()
+    return a
 
 
 def _f32c(t):
@@ -70,9 +107,23 @@ def _staged(fn):
     return wrapper
 
 
+def _on_device(fn):
+    """CUDA-key implementation: the C-ABI acts on the CURRENT device (launch configuration caches, the CU count), so make
+    the tensors' device current when it is not (a tensor on cuda:1 while cuda:0 is current)."""
+    def wrapper(*args):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args)
+                break
+        return fn(*args)
+    return wrapper
+
+
 def _impl(name, fn, mutates=lambda a, args: False):
     fn._mutates = mutates
-    _DEF.impl(name, fn, "CUDA")
+    _DEF.impl(name, _on_device(fn), "CUDA")
     _DEF.impl(name, _staged(fn), "CPU")
 
 
@@ -143,6 +194,18 @@ def set_stage_timer(handle):
     _stage_timer = handle
 
 
+# Opt-in "a8" mode of the fp8 path (sglk.h: SGLK_MOE_FP8_ACT): fp8 activations on the block-scaled fp8 matrix cores.  NOT
+# the reference's W8A16 numerics, never a default: switched on by SGLK_FP8_ACT=1 in the environment at import, or by
+# set_fp8_activations(True).
+_fp8_act = os.environ.get("SGLK_FP8_ACT", "0") not in ("", "0")
+last_path = 0   # sglk_fused_experts' path_taken of the most recent call (measurement reports)
+
+
+def set_fp8_activations(on):
+    global _fp8_act
+    _fp8_act = bool(on)
+
+
 # sglang.srt.layers.amx_utils.CPUQuantMethod values (shim in sgl-cpu-tests_amd/sglang)
 UNQUANT, INT8_W8A8, FP8_W8A16 = 0, 1, 2
 
@@ -192,8 +255,12 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
     out = hidden_states_c if (inplace and hidden_states_c is hidden_states) else torch.empty_like(hidden_states_c)
     L = _lib.lib()
     wtype = _WTYPE[wdtype]
-    ws_bytes = L.sglk_fused_experts_workspace_bytes(M, N, K, E, topk, wtype)
+    flags = _lib.MOE_FP8_ACT if (_fp8_act and int(method) == FP8_W8A16) else 0
+    ws_bytes = L.sglk_fused_experts_workspace_bytes_ex(M, N, K, E, topk, wtype, flags)
     ws = _workspace(ws_bytes, hidden_states.device)
+    # second stream for the tail tiles: only the batch sizes that have them (full 256-row tiles plus short tails)
+    aux = _aux(hidden_states.device) if (int(method) == FP8_W8A16 and 72 * E <= M * topk < 640 * E) else None
+    path = ctypes.c_int32(0)
     args = _lib.FusedExpertsArgs(
         hidden=hidden_states_c.data_ptr(), hidden_stride=hidden_states_c.stride(0),
         out=out.data_ptr(), out_stride=out.stride(0),
@@ -203,9 +270,14 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
         topk_weights=topk_weights.data_ptr(), topk_ids=topk_ids.data_ptr(),
         M=M, N=N, K=K, E=E, topk=topk, wtype=wtype,
         packed=_packed_bits(is_vnni, (2 * N, K), (K, N), wdtype),
-        block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=_stage_timer)
+        block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=_stage_timer,
+        aux_stream=aux.stream if aux else None,
+        aux_events=(ctypes.c_void_p * 2)(aux.ev0, aux.ev1) if aux else (ctypes.c_void_p * 2)(),
+        flags=flags, path_taken=ctypes.pointer(path))
     rc = L.sglk_fused_experts(ctypes.byref(args), _stream(hidden_states))
     _lib.check(rc, "fused_experts_cpu")
+    global last_path
+    last_path = path.value
     if inplace and out is not hidden_states:
         hidden_states.copy_(out)
         return hidden_states
@@ -283,7 +355,7 @@ def shared_expert_cpu(hidden_states, w1, w2, fused_experts_out, routed_scaling_f
     L = _lib.lib()
     wtype = _WTYPE[wdtype]
     ws_bytes = L.sglk_shared_expert_workspace_bytes(M, N, K, wtype)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=hs.device)
+    ws = _workspace(ws_bytes, hs.device)
     args = _lib.SharedExpertArgs(
         hidden=hs.data_ptr(), hidden_stride=hs.stride(0), out=out.data_ptr(), out_stride=out.stride(0),
         w1=w1.data_ptr(), w2=w2.data_ptr(),
@@ -349,7 +421,7 @@ def _scaled_mm(x, w, w_scale, bias, out_dtype, is_vnni, block, x_scale=None):
     L = _lib.lib()
     wtype = _WTYPE[w.dtype]
     ws_bytes = L.sglk_scaled_mm_workspace_bytes(M, N, K, wtype, int(x_is_int8))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    ws = _workspace(ws_bytes, x.device)
     args = _lib.ScaledMmArgs(
         x=x.data_ptr(), x_stride=x.stride(0), x_is_int8=int(x_is_int8),
         x_scale=x_scale.data_ptr() if x_scale is not None else None, w=w.data_ptr(),

@@ -35,3 +35,24 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture
+def knob(monkeypatch):
+    """Sets SGLK_* developer knobs for ONE test: `knob(SGLK_MOE_TILE_M=96, SGLK_PERSIST=None)` (None = unset).
+
+    The library reads its environment once (sgl-cpu-tests_amd/csrc/knobs.h); sglk_reload_env() makes it look again, here
+    after every change and once more when the test is over, so no knob leaks into the next test."""
+    from sgl_kernel import _lib
+
+    def set_knobs(**kw):
+        for k, v in kw.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _lib.lib().sglk_reload_env()
+
+    yield set_knobs
+    monkeypatch.undo()
+    _lib.lib().sglk_reload_env()

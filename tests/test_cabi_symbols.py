@@ -21,7 +21,7 @@ def test_header_symbols_are_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/sglk.h but not exported by libsglk.so"
         assert s in sgl_kernel._lib._SIGNATURES, f"{s} has no ctypes signature in sgl_kernel/_lib.py"
-    assert lib.sglk_version() == 100
+    assert lib.sglk_version() == 200
 
 
 def test_ops_registered_with_reference_signatures():

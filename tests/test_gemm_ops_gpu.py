@@ -324,7 +324,7 @@ def test_fused_experts_bf16_on_mid_kernel(ops, shape):
     assert torch.equal(out, again)
 
 
-def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):
+def test_fp8_generic_engine_matches_tuned_kernels(ops, knob):
     """Same fp8 fused_experts inputs through the tuned path and (forced) through the generic engine."""
     name, M, N, K, E, topk, bn, bk, masked, seed, full = recipes.MOE_FP8_CASES[1]
     g, _ = load_golden("moe_fp8_" + name)
@@ -332,7 +332,7 @@ def test_fp8_generic_engine_matches_tuned_kernels(ops, monkeypatch):
     w1p, w2p = ops.convert_weight_packed(inp["w1"]), ops.convert_weight_packed(inp["w2"])
     args = (inp["topk_weight"], inp["topk_ids"], False, False, True, inp["w1s"], inp["w2s"], [bn, bk], None, None)
     tuned = ops.fused_experts_cpu(inp["a"], w1p, w2p, *args, True)
-    monkeypatch.setenv("SGLK_FORCE_GENERIC", "1")
+    knob(SGLK_FORCE_GENERIC=1)
     generic_packed = ops.fused_experts_cpu(inp["a"], w1p, w2p, *args, True)
     generic_plain = ops.fused_experts_cpu(inp["a"], inp["w1"], inp["w2"], *args, False)     # is_vnni=False
     assert torch.equal(generic_packed, generic_plain)

@@ -149,10 +149,10 @@ def test_cpu_tensors_are_staged_through_the_gpu(ops):
 
 @pytest.mark.parametrize("tile_m", ["32", "96", "128", "256"])
 @pytest.mark.parametrize("block", [(128, 128), (64, 128)])
-def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
+def test_fused_experts_fp8_tile_variants(ops, tile_m, block, knob):
     """Every grouped-GEMM tiling (32- and 96-row weight streaming, 128-row 2-stage, 256-row 3-deep ring) against the plain-C oracle; ragged expert
     loads (rows per expert not a multiple of either tile), wide dynamic range of block scales incl. zero/negative."""
-    monkeypatch.setenv("SGLK_MOE_TILE_M", tile_m)
+    knob(SGLK_MOE_TILE_M=tile_m)
     M, N, K, E, topk = 1531, 256, 512, 8, 4
     bn, bk = block
     inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 9001)
@@ -172,10 +172,11 @@ def test_fused_experts_fp8_tile_variants(ops, tile_m, block, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["0", "1", "2"])
-def test_fused_experts_fp8_tail_tiles(ops, mode, monkeypatch):
-    """Experts with one full 256-row tile plus a short tail (rows ~ 300): the tails run on the mid kernel -- off, on the
-    caller's stream, or on the library's side stream (same bits as on the caller's); also under hipGraph capture."""
-    monkeypatch.setenv("SGLK_TAIL_SPLIT", mode)
+def test_fused_experts_fp8_tail_tiles(ops, mode, knob):
+    """Experts with one full 256-row tile plus a short tail (rows ~ 300): the tails run on the mid kernel -- off ("0"), on the
+    caller's stream ("1"), or (default, "2") on the aux stream the Python layer owns and passes in (same bits as on the
+    caller's); also under hipGraph capture."""
+    knob(SGLK_TAIL_SPLIT=None if mode == "2" else mode)
     M, N, K, E, topk, block = 600, 256, 512, 8, 4, (128, 128)
     inp = recipes.moe_fp8_inputs(M, N, K, E, topk, block[0], block[1], False, 9055)
     ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], block,
@@ -208,11 +209,11 @@ def test_fused_experts_fp8_tail_tiles(ops, mode, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(200, 384, 640, 8, 2), (64, 256, 4352, 4, 2), (300, 384, 7168, 8, 4)],
                          ids=lambda s: "M%d_N%d_K%d_E%d_top%d" % s)
-def test_fused_experts_fp8_mid_odd_and_long_reductions(ops, shape, monkeypatch):
+def test_fused_experts_fp8_mid_odd_and_long_reductions(ops, shape, knob):
     """The weight-streaming mid kernel beyond the Qwen3 shape: odd numbers of 128-wide K blocks (N = 384 -> 3, K = 640 -> 5)
     and more than 32 of them (K = 4352 -> 34, K = 7168 -> 56: the reference bench's literal expert shape), against the
     plain-C oracle."""
-    monkeypatch.setenv("SGLK_MOE_TILE_M", "96")
+    knob(SGLK_MOE_TILE_M=96)
     M, N, K, E, topk = shape
     block = (128, 128)
     inp = recipes.moe_fp8_inputs(M, N, K, E, topk, block[0], block[1], False, 9077 + M)
