@@ -154,7 +154,9 @@ def main():
             return out
     else:
         from sgl_kernel.expert_parallel import ExpertParallelMoE
-        ep = ExpertParallelMoE(N_EXPERTS, local_experts)
+        # SGLK_EP_CAPACITY=c (0 < c <= 1): fixed segments of ceil(c * tokens) rows per destination, no host read of the counts
+        cap_env = os.environ.get("SGLK_EP_CAPACITY")
+        ep = ExpertParallelMoE(N_EXPERTS, local_experts, capacity_factor=float(cap_env) if cap_env else None, profile=True)
 
         def step():
             out = ep(inputs[step_idx[0] % n_inputs], tw, ids)
@@ -193,6 +195,8 @@ def main():
     run_steps(prime)
     run_steps(args.warmup)
     barrier()
+    if world > 1:
+        ep.phase_ms()      # drop the warm-up steps' phase events
     _ops.set_stage_timer(timer)
     L.sglk_stage_timer_reset(timer)
     t0 = time.perf_counter()
@@ -222,7 +226,13 @@ def main():
         PEAK_FP8 = 5000.0
         _ops.set_fp8_activations(True)
         try:
-            run_steps(6)
+            def refresh():      # every step again reads pristine tokens (inplace=True has overwritten the clones)
+                for t in inputs:
+                    t.copy_(a)
+                step_idx[0] = 0
+            refresh()
+            run_steps(min(6, n_inputs))
+            refresh()
             torch.cuda.synchronize()
             L.sglk_stage_timer_reset(timer)
             _ops.set_stage_timer(timer)
@@ -254,8 +264,8 @@ def main():
                 ref = c_oracle.fused_experts_fp8(a[sample].cpu(), w_host[0], w_host[1], w1s.cpu(), w2s.cpu(), BLOCK,
                                                  tw[sample].cpu(), ids[sample].cpu())
                 rel = ((got - ref).norm() / ref.norm().clamp_min(1e-12)).item()
-                res["tolerance"] = {"stated": "relative RMS < 2e-2 against the quantised-arithmetic oracle (oracle/moe_a8.py)",
-                                    "rel_rms_vs_quantised_oracle": round(rel_q, 5), "ok": rel_q < 2e-2,
+                res["tolerance"] = {"stated": "relative RMS < 5e-3 against the quantised-arithmetic oracle (oracle/moe_a8.py)",
+                                    "rel_rms_vs_quantised_oracle": round(rel_q, 5), "ok": rel_q < 5e-3,
                                     "rel_rms_vs_w8a16_oracle": round(rel, 5),
                                     "reference_predicate_vs_w8a16_oracle": bool(
                                         torch.allclose(ref.bfloat16(), got.bfloat16(), rtol=1e-2, atol=1e-2)),
@@ -345,6 +355,11 @@ def main():
                                  "bf16 MFMA, so the dense bf16 peak (2.5 PF) is the governing roof"},
             "stage_ms": stage_ms,
         }
+        if world > 1:
+            # rank 0's view of the exchange: mean ms per phase over the timed steps (HIP events on each step's stream) and the
+            # bytes one step moves out of / back into this GPU
+            line["ep"] = {"phase_ms": ep.phase_ms(), "split_mode": "fixed capacity, no host read" if ep.capacity_factor else
+                          "exact counts, one host read per step", **ep.last_stats}
         if world == 1 and args.a8:
             try:
                 line["a8"] = bench_a8()

@@ -220,6 +220,20 @@ typedef struct {
 size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
 int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
 
+/* Expert-parallel dispatch glue (sgl_kernel/expert_parallel.py; no reference counterpart -- the reference pins only the
+ * local contract EP needs, topk_ids == -1 for non-resident experts: /root/reference/test_moe_offloading_cpu.py:12-15,62-68).
+ * Rank d owns experts [d*E/G, (d+1)*E/G).
+ * sglk_ep_plan: counts[d] = tokens with at least one slot on rank d; pos[m][d] = index of token m among them in ascending
+ *   token order (-1: not sent); seg_start[G+1] = first payload row of every destination: exclusive sums of counts
+ *   (capacity == 0), or d * capacity (capacity > 0: fixed-size segments, no host read of the counts needed; *overflow gets
+ *   bit d when counts[d] > capacity, the surplus tokens are dropped).
+ * sglk_ep_pack: payload row (seg_start[d] + pos[m][d]) = [K bf16 of token m | topk ids in d's numbering, -1 elsewhere |
+ *   topk routing weights f32], row_bytes >= 2K + 8 topk and a multiple of 16; capacity > 0: ids of unused rows = -1. */
+int sglk_ep_plan(const int32_t* topk_ids, int32_t M, int32_t topk, int32_t E, int32_t G, int32_t capacity, int32_t* counts,
+                 int32_t* seg_start, int32_t* pos, int32_t* overflow, void* stream);
+int sglk_ep_pack(const void* hidden, int64_t hidden_stride, const int32_t* topk_ids, const float* topk_weights,
+                 const int32_t* pos, const int32_t* seg_start, const int32_t* counts, void* payload, int64_t row_bytes, int32_t M,
+                 int32_t K, int32_t topk, int32_t E, int32_t G, int32_t capacity, void* stream);
 /* Expert-parallel combine (no reference counterpart: the exchange around fused_experts):
  * out[m][:] = sum over d = 0..G-1 ascending of rows[table[m*G + d]][:] for table entries >= 0; bf16 rows, fp32 sum, one
  * bf16 rounding.  K % 8 == 0, strides in elements (multiples of 8). */

@@ -33,8 +33,8 @@ int pick_tile_m(int M, int N, int K, int E, int topk, int block_n, int64_t hidde
     const Knobs& kn = knobs();
     const int64_t S = (int64_t)M * topk;
     // the 256 kernel addresses its operands through 32-bit buffer offsets (the rows of `hidden` by their STRIDE, which a
-    // row-strided view makes larger than K) and walks the scale table in 32-row operand tiles
-    const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && block_n % 32 == 0 && S * (int64_t)N * 2 < (1ll << 32) &&
+    // row-strided view makes larger than K), walks the scale table in 32-row operand tiles and needs two K blocks per GEMM
+    const bool ok256 = (K % 256 == 0) && (N % 128 == 0) && N >= 256 && block_n % 32 == 0 && S * (int64_t)N * 2 < (1ll << 32) &&
                        (int64_t)M * hidden_stride * 2 < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32);
     // stream kernel: both reduction lengths (K for GEMM-1, N for GEMM-2) must be multiples of 256 (ring of 8 pieces)
     const bool ok_stream = (K % 256 == 0) && (N % 256 == 0) && (int64_t)kStreamTileM * K * 2 <= 150 * 1024 &&
@@ -209,7 +209,7 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     const bool tuned = tuned_fp8_ok(a);
     const bool a8 = (a->flags & SGLK_MOE_FP8_ACT) != 0;
     if (a8) {   // an explicit request: refuse what the a8 kernels cannot take instead of answering with other numerics
-        SGLK_REQUIRE(tuned && K % 256 == 0 && N % 128 == 0 && a->block_n % 32 == 0 && K <= 4096 && N <= 4096 &&
+        SGLK_REQUIRE(tuned && K % 256 == 0 && N % 128 == 0 && N >= 256 && a->block_n % 32 == 0 && K <= 4096 && N <= 4096 &&
                          (int64_t)M * K < (1ll << 32) && (int64_t)M * topk * N < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32),
                      SGLK_ERR_SHAPE, "fused_experts: SGLK_MOE_FP8_ACT needs packed fp8 weights, block [32k,128], K %% 256 == 0, "
                      "N %% 128 == 0, K,N <= 4096 (got N=%d K=%d block_n=%d packed=%d)", N, K, a->block_n, a->packed);

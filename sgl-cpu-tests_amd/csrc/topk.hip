@@ -8,7 +8,11 @@
 // One wave per token, everything in fp32.  Tie rule (the reference's torch.topk leaves it open): larger value
 // first, equal values -> lower index first; experts of non-selected groups are only taken when the selected groups
 // hold fewer than topk experts, and then carry weight 0 (softmax variant, matching masked_fill(0.0)).
-// Output order: descending choice.  Integer results are compared bit-exactly against this repo's oracle.
+// Softmax variant: softmax is monotone, so groups and experts are RANKED BY THE LOGITS (exact comparisons of the inputs)
+// and only the returned weights go through exp(): the ids do not depend on anybody's exp rounding and equal this repo's
+// oracle bit for bit (oracle/routing.py ranks equal fp32 scores by logit, then index -- a refinement of the open tie rule).
+// Sigmoid + bias variant: the ranking key sigmoid(x) + bias is a rounded quantity; ids equal the oracle's except on
+// genuine near-ties of that key (asserted as such in tests/test_rows_topk_gpu.py).  Output order: descending key.
 #include "sglk_common.h"
 
 namespace sglk {
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
     for (int j = 0; j < kPerLane; ++j) {
         const int e = j * 64 + lane;
         score[j] = e < E ? ld_gate<GT>(gating, (int64_t)m * g_stride + e) : -INFINITY;
+        choice[j] = score[j];   // softmax variant: the ranking key is the logit itself
         mx = fmaxf(mx, score[j]);
     }
     if (!BIASED) {
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         }
         sum = wave_sum(sum);
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) { score[j] /= sum; choice[j] = score[j]; }
+        for (int j = 0; j < kPerLane; ++j) score[j] /= sum;
     } else {
 #pragma unroll
         for (int j = 0; j < kPerLane; ++j) {

@@ -269,6 +269,39 @@ def gen_attn():
                   input_sha256=checksum(inp["q"], inp["k_buffer"], inp["key"], inp["loc"])))
 
 
+def gen_attn_big():
+    """BASELINE.json config 3 sizes (seqlen <= 8k): the reference oracle runs on the whole problem, the golden keeps its
+    output for a sample of token rows (all heads) -- the inputs are regenerated from the seed by tests/recipes.py."""
+    from torch.nn.functional import scaled_dot_product_attention
+    ns = lift("test_extend.py", ["_run_sdpa_forward_extend"], {"scaled_dot_product_attention": scaled_dot_product_attention})
+    for name, B, N_CTX, HQ, HKV, D, DV, mla, seed in recipes.EXTEND_BIG_CASES:
+        inp = recipes.extend_inputs_fixed(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+        T = inp["q_extend"].shape[0]
+        o_ref = torch.empty(T, HQ, DV, dtype=torch.bfloat16)
+        ns["_run_sdpa_forward_extend"](inp["q_extend"], o_ref, inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"],
+                                       inp["b_req_idx"], inp["b_seq_len"], inp["b_prefix"], inp["b_extend"],
+                                       scaling=1.0 / D ** 0.5, enable_gqa=HQ != HKV, causal=True)
+        rows = recipes.sample_rows(T, 160, seed)
+        save("extend_" + name, {"rows": rows, "ref_out_rows": o_ref[rows].clone()},
+             dict(B=B, N_CTX=N_CTX, HQ=HQ, HKV=HKV, D=D, DV=DV, mla=int(mla), seed=seed, tokens=T,
+                  input_sha256=checksum(inp["q_extend"], inp["k_buffer"], inp["v_buffer"], inp["req_to_tokens"])))
+    nsd = lift("test_mla.py", ["_run_sdpa_forward_decode"], {"scaled_dot_product_attention": scaled_dot_product_attention})
+    for name, B, HQ, HKV, D, DV, seq_len, v_alias, seed in recipes.DECODE_BIG_CASES:
+        inp = recipes.decode_inputs(B, HQ, HKV, D, DV, seq_len, v_alias, seed)
+        kb = inp["k_buffer"].clone()
+        if v_alias:
+            vb, value = kb.narrow(2, 0, DV), inp["key"].narrow(2, 0, DV)
+        else:
+            vb, value = inp["v_buffer"].clone(), inp["value"]
+            vb[inp["loc"]] = value
+        o_ref = torch.zeros(B, HQ, DV, dtype=torch.bfloat16)
+        nsd["_run_sdpa_forward_decode"](inp["q"], o_ref, kb, vb, inp["key"], inp["loc"], inp["req_to_token"],
+                                        inp["b_req_idx"], inp["b_seq_len"], scaling=1.0 / D ** 0.5, enable_gqa=HQ != HKV)
+        save("decode_" + name, {"ref_out": o_ref},
+             dict(B=B, HQ=HQ, HKV=HKV, D=D, DV=DV, seq_len=seq_len, v_alias=int(v_alias), seed=seed,
+                  input_sha256=checksum(inp["q"], inp["key"], inp["loc"])))
+
+
 def gen_absorb():
     """qkv_proj_with_rope: native_torch / native_torch_int8 of /root/reference/test_absorb.py:65-109 (and their helpers
     :20-63), run with the file's own module constants (:10-17)."""
@@ -334,7 +367,7 @@ def gen_mxfp4():
         save("mxfp4_" + name, tensors, dict(M=M, N=N, K=K, kind=kind, seed=seed, input_sha256=checksum(inp["a"], inp["wq"], inp["ws"])))
 
 
-FAMILIES = {"moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
+FAMILIES = {"attn_big": gen_attn_big, "moe_fp8": gen_moe_fp8, "moe_int8": gen_moe_int8, "moe_bf16": gen_moe_bf16, "topk": gen_topk, "gemm": gen_gemm,
             "shared": gen_shared, "rows": gen_rows, "attn": gen_attn, "absorb": gen_absorb, "varlen": gen_varlen, "bmm": gen_bmm, "mxfp4": gen_mxfp4}
 
 

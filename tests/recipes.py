@@ -268,6 +268,62 @@ DECODE_CASES = [
 ]
 
 
+# The sizes BASELINE.json config 3 names (seqlen <= 8k), as /root/reference/bench_extend.py:107-112 and
+# /root/reference/test_mla.py:178-186 run them: prefix and extend fifty-fifty (MLA: no prefix), fixed lengths.  Too large to
+# store: the goldens keep the reference oracle's output for a sample of token rows (`rows`), the inputs come from the seed.
+# name, B, N_CTX, H_Q, H_KV, D, DV, mla, seed
+EXTEND_BIG_CASES = [
+    ("bench_b1_ctx4096_hq32_hkv4", 1, 4096, 32, 4, 128, 128, False, 7121),     # Qwen3-30B-A3B heads, bench_extend.py:107
+    ("bench_b1_ctx8192_hq16_hkv2", 1, 8192, 16, 2, 128, 128, False, 7122),     # bench_extend.py:108
+    ("bench_b4_ctx3500_hq22_mla_d192", 4, 3500, 22, 22, 192, 128, True, 7123),  # bench_extend.py:111-112
+]
+# name, B, H_Q, H_KV, D, DV, seq_len, v_alias, seed
+DECODE_BIG_CASES = [
+    ("mla_b40_s4096", 40, 22, 1, 576, 512, 4096, True, 7221),
+    ("gqa_b64_hq32_hkv4_s4096", 64, 32, 4, 128, 128, 4096, False, 7222),
+]
+
+
+def extend_inputs_fixed(B, N_CTX, H_Q, H_KV, D, DV, mla, seed):
+    """/root/reference/bench_extend.py:22-56: every sequence has prefix N_CTX/2 + extend N_CTX/2 (MLA: extend N_CTX)."""
+    g = _gen(seed)
+    dt = torch.bfloat16
+    prefix = torch.full((B,), 0 if mla else N_CTX // 2, dtype=torch.int32)
+    extend = torch.full((B,), N_CTX if mla else N_CTX // 2, dtype=torch.int32)
+    seq = prefix + extend
+    req_to_tokens = torch.zeros(B, int(seq.max()), dtype=torch.int32)
+    start = torch.zeros(B, dtype=torch.int32)
+    start[1:] = torch.cumsum(seq[:-1], 0)
+    start_ext = torch.zeros(B, dtype=torch.int32)
+    start_ext[1:] = torch.cumsum(extend[:-1], 0)
+    for i in range(B):
+        req_to_tokens[i, :seq[i]] = torch.arange(int(start[i]), int(start[i] + seq[i]))
+    total, ext_total = int(seq.sum()), int(extend.sum())
+    HB = 1 if mla else H_KV
+    k_buffer = torch.randn(total, HB, D, generator=g).to(dt)
+    v_buffer = torch.randn(total, HB, DV, generator=g).to(dt)
+    k_extend = torch.empty(ext_total, H_KV, D, dtype=dt)
+    v_extend = torch.empty(ext_total, H_KV, DV, dtype=dt)
+    q_extend = torch.randn(ext_total, H_Q, D, generator=g).to(dt)
+    for i in range(B):
+        s0, e0 = int(start[i] + prefix[i]), int(start[i] + seq[i])
+        s1, e1 = int(start_ext[i]), int(start_ext[i] + extend[i])
+        k_extend[s1:e1] = k_buffer[s0:e0]
+        v_extend[s1:e1] = v_buffer[s0:e0]
+    return dict(q_extend=q_extend, k_extend=k_extend, v_extend=v_extend, k_buffer=k_buffer, v_buffer=v_buffer,
+                req_to_tokens=req_to_tokens, b_req_idx=torch.arange(B, dtype=torch.int64), b_seq_len=seq.to(torch.int64),
+                b_prefix=prefix, b_extend=extend, b_start_loc_extend=start_ext)
+
+
+def sample_rows(n, count, seed):
+    """`count` row indices of 0..n-1: both ends, both sides of every 128-row block edge near the ends, random in between."""
+    g = _gen(seed)
+    fixed = [0, 1, 127, 128, 129, n // 2 - 1, n // 2, n - 130, n - 129, n - 128, n - 2, n - 1]
+    fixed = sorted({r for r in fixed if 0 <= r < n})
+    rest = torch.randperm(n, generator=g)[: max(0, count - len(fixed))].tolist()
+    return torch.tensor(sorted(set(fixed) | set(rest)), dtype=torch.long)
+
+
 def extend_inputs(B, N_CTX, H_Q, H_KV, D, DV, mla, seed):
     """/root/reference/test_extend.py:79-138."""
     g = _gen(seed)

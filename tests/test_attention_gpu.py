@@ -117,3 +117,60 @@ def test_decode_attention_ragged_lengths_and_int32_index(ops):
     assert torch.equal(kbd.cpu(), kb2) and torch.equal(vbd.cpu(), vb2)
     assert torch.allclose(o.cpu().float(), ref, atol=3e-2)
     assert (o.float().cpu() - ref).norm() / ref.norm() < 6e-3
+
+
+# ---- BASELINE.json config 3 at its own sizes (seqlen <= 8k): /root/reference/bench_extend.py:107-112, test_mla.py:178-186 ----
+@pytest.mark.parametrize("case", recipes.EXTEND_BIG_CASES, ids=lambda c: c[0])
+def test_extend_attention_bench_sizes(ops, case):
+    """The shapes the reference benches (ctx 4096 x 32/4 heads, 8192 x 16/2, MLA-like prefill 4 x 3500 x 22 heads, D=192):
+    every row computed on the GPU; the golden holds the reference oracle's (_run_sdpa_forward_extend) output for ~160
+    sampled token rows x all heads -- both ends of the sequence, block edges, random rows in between."""
+    name, B, N_CTX, HQ, HKV, D, DV, mla, seed = case
+    g, meta = load_golden("extend_" + name)
+    inp = recipes.extend_inputs_fixed(B, N_CTX, HQ, HKV, D, DV, mla, seed)
+    T = inp["q_extend"].shape[0]
+    assert T == int(meta["tokens"])
+    d = cuda(inp)
+    o = torch.full((T, HQ, DV), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ret = ops.extend_attention_cpu(d["q_extend"], d["k_extend"], d["v_extend"], o, d["k_buffer"], d["v_buffer"],
+                                   d["req_to_tokens"], d["b_req_idx"], d["b_seq_len"], d["b_extend"],
+                                   d["b_start_loc_extend"], int(inp["b_extend"].max()), 1.0 / D ** 0.5, 0.0)
+    assert ret is None
+    assert torch.isfinite(o.float()).all(), "a row was not written"
+    rows = g["rows"]
+    got = o[rows.cuda()].cpu()
+    assert torch.allclose(g["ref_out_rows"], got, rtol=1e-2, atol=1e-2), name        # utils.compare, test_extend.py:188
+    ref = g["ref_out_rows"].float()
+    err = (got.float() - ref).norm() / ref.norm()
+    assert err < 8e-3, f"{name}: relative RMS error {err:.2e} against the (bf16-rounded) reference output"
+
+
+@pytest.mark.parametrize("case", recipes.DECODE_BIG_CASES, ids=lambda c: c[0])
+def test_decode_attention_seq4096(ops, case):
+    """Decode over 4096 cached keys: MLA B=40 (test_mla.py:178-186 at the config's length) and GQA B=64; reference predicates
+    (cosine similarity > 0.99, allclose(atol=3e-2), bit-exact cache write) against the reference oracle's whole output."""
+    name, B, HQ, HKV, D, DV, seq_len, v_alias, seed = case
+    g, _ = load_golden("decode_" + name)
+    inp = recipes.decode_inputs(B, HQ, HKV, D, DV, seq_len, v_alias, seed)
+    kb = inp["k_buffer"].cuda()
+    key = inp["key"].cuda()
+    if v_alias:
+        vb, value = kb.narrow(2, 0, DV), key.narrow(2, 0, DV)
+    else:
+        vb, value = inp["v_buffer"].cuda(), inp["value"].cuda()
+    o = torch.zeros(B, HQ, DV, dtype=torch.bfloat16, device="cuda")
+    logits = torch.empty(B, HQ, 8, DV + 1, dtype=torch.float32, device="cuda")
+    ops.decode_attention_cpu(inp["q"].cuda(), kb, vb, o, key, value, inp["loc"].cuda(), logits,
+                             inp["req_to_token"].cuda(), inp["b_req_idx"].cuda(), inp["b_seq_len"].cuda(), 1.0 / D ** 0.5, 0.0)
+    ref = g["ref_out"].float()
+    cos = torch.nn.functional.cosine_similarity(o.float().cpu().flatten(), ref.flatten(), dim=0)
+    assert cos > 0.99, f"{name}: cos_sim {cos}"
+    assert torch.allclose(o.cpu().float(), ref, atol=3e-2), name
+    err = (o.float().cpu() - ref).norm() / ref.norm()
+    assert err < 1e-2, f"{name}: relative RMS error {err:.2e} against the (bf16-rounded) reference output"
+    rows = inp["loc"]
+    assert torch.equal(kb[rows.cuda()].cpu(), inp["key"]), "KV-cache write"
+    untouched = torch.ones(kb.shape[0], dtype=torch.bool)
+    untouched[rows] = False
+    sel = torch.nonzero(untouched).flatten()[:: max(1, kb.shape[0] // 4096)]
+    assert torch.equal(kb[sel.cuda()].cpu(), inp["k_buffer"][sel]), "rows other than `loc` must stay as they were"

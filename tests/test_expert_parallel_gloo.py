@@ -1,8 +1,9 @@
-"""world_size-2 gloo test (CPU) of the expert-parallel exchange logic (sgl_kernel/expert_parallel.py).
+"""Multi-process gloo tests (CPU) of the expert-parallel exchange (sgl_kernel/expert_parallel.py), world sizes 2 and 4.
 
 The communication plan, the id rewriting to local numbering with -1 padding
-(/root/reference/test_moe_offloading_cpu.py:62-68) and the fixed-order combine are device-agnostic; here the
-local experts are played by the oracle (test infrastructure) so the whole exchange can be checked without a GPU."""
+(/root/reference/test_moe_offloading_cpu.py:62-68), the single-payload dispatch and the fixed-order combine are
+device-agnostic; here the local experts are played by the oracle (test infrastructure) so the whole exchange can be checked
+without a GPU, in both split modes (exact counts with one host read; fixed-capacity segments with none)."""
 import os
 import sys
 
@@ -14,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, scenario):
     for p in (ROOT, os.path.join(ROOT, "sgl-cpu-tests_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -26,41 +27,88 @@ def _worker(rank, world, port, ret):
         from sgl_kernel.expert_parallel import ExpertParallelMoE, masked_allgather_reference
         M, N, K, E, topk, bn, bk = 37, 128, 128, 8, 3, 128, 128
         full = recipes.moe_fp8_inputs(M * world, N, K, E, topk, bn, bk, False, 5150)   # identical on every rank
-        full["topk_ids"][3, 1] = -1                                                     # a padded slot survives EP
+        ids_all = full["topk_ids"]
+        ids_all[3, 1] = -1                                                             # a padded slot survives EP
+        if scenario == "skewed":
+            # every slot of every token goes to the experts of rank 0 and of the LAST rank only: the ranks in between receive
+            # zero rows; one token is all -1 (sent nowhere); rank 1's tokens all pick the same expert
+            epr = E // world
+            g = torch.Generator().manual_seed(77)
+            pick = torch.randint(0, 2, ids_all.shape, generator=g)
+            ids_all[:] = torch.where(pick == 0, torch.randint(0, epr, ids_all.shape, generator=g),
+                                     (world - 1) * epr + torch.randint(0, epr, ids_all.shape, generator=g)).to(torch.int32)
+            ids_all[5] = -1
+            ids_all[M:2 * M] = 0
+            ids_all[M + 1, 2] = -1
         sl = slice(rank * M, (rank + 1) * M)
-        a, tw, ids = full["a"][sl], full["topk_weight"][sl], full["topk_ids"][sl]
+        a, tw, ids = full["a"][sl], full["topk_weight"][sl], ids_all[sl]
         epr = E // world
         lo = rank * epr
         w1, w2 = full["w1"][lo:lo + epr], full["w2"][lo:lo + epr]
         w1s, w2s = full["w1s"][lo:lo + epr], full["w2s"][lo:lo + epr]
+        received = []
 
         def local(h, w, lids):
-            return moe.fused_experts_fp8(h, w1, w2, w1s, w2s, (bn, bk), w, lids).bfloat16()
+            received.append(int(h.shape[0]))
+            if h.shape[0] == 0:
+                return torch.zeros(0, K, dtype=torch.bfloat16)
+            return moe.fused_experts_fp8(h.contiguous(), w1, w2, w1s, w2s, (bn, bk), w, lids).bfloat16()
 
-        ep = ExpertParallelMoE(E, local)
-        out = ep(a, tw, ids)
         ref_full = moe.fused_experts_fp8(full["a"], full["w1"], full["w2"], full["w1s"], full["w2s"], (bn, bk),
-                                         full["topk_weight"], full["topk_ids"])[sl]
+                                         full["topk_weight"], ids_all)[sl]
+        # |EP - one-GPU| <= 2^-8 * (sum over ranks |partial_d| + |result|): every rank rounds its partial sum to bf16 once,
+        # the fp32 sum of the partials is rounded once more (module docstring)
+        bound = ref_full.abs().clone()
+        for d in range(world):
+            masked = torch.where((ids >= d * epr) & (ids < (d + 1) * epr), ids, torch.full_like(ids, -1))
+            bound += moe.fused_experts_fp8(a, full["w1"], full["w2"], full["w1s"], full["w2s"], (bn, bk), tw, masked).abs()
+        bound = bound * 2.0 ** -8 + 1e-30
+
+        res = {}
+        for mode, cf in (("exact", None), ("capacity", 1.0)):
+            received.clear()
+            ep = ExpertParallelMoE(E, local, capacity_factor=cf)
+            out = ep(a, tw, ids)
+            ok_pred = torch.allclose(ref_full.bfloat16(), out, rtol=1e-2, atol=1e-2)
+            ok_bound = bool(((out.float() - ref_full).abs() <= bound * 1.01).all())
+            res[mode] = (out, ok_pred, ok_bound, dict(ep.last_stats), list(received), int(ep.last_overflow[0]))
+        out_e, out_c = res["exact"][0], res["capacity"][0]
+        same = torch.equal(out_e, out_c)                      # the two split modes move the same rows: identical bits
         alt = masked_allgather_reference(a, tw, ids, E, local)
-        ok1 = torch.allclose(ref_full.bfloat16(), out, rtol=1e-2, atol=1e-2)
-        ok2 = torch.allclose(alt.float(), out.float(), rtol=2e-2, atol=1e-3)
-        # every token row is sent at most once per destination rank
-        tok, rk, cnt = ep.plan(ids)
-        ok3 = len(set(zip(tok.tolist(), rk.tolist()))) == tok.numel() and int(cnt.sum()) == tok.numel()
-        ret[rank] = (bool(ok1), bool(ok2), bool(ok3), ep.last_stats["rows_sent"])
+        ok_alt = torch.allclose(alt.float(), out_e.float(), rtol=2e-2, atol=1e-3)
+        # plan: every token row is sent at most once per destination rank, in ascending token order
+        ep = ExpertParallelMoE(E, local)
+        counts, seg_start, pos = ep.plan(ids)
+        ok_plan = True
+        for d in range(world):
+            p = pos[:, d][pos[:, d] >= 0]
+            ok_plan &= p.tolist() == list(range(int(counts[d])))
+            want = ((ids >= d * epr) & (ids < (d + 1) * epr)).any(dim=1)
+            ok_plan &= torch.equal(pos[:, d] >= 0, want)
+        ret[rank] = dict(pred=(res["exact"][1], res["capacity"][1]), bound=(res["exact"][2], res["capacity"][2]), same=same,
+                         alt=bool(ok_alt), plan=bool(ok_plan), stats=res["exact"][3], cap_stats=res["capacity"][3],
+                         received=res["exact"][4], overflow=res["capacity"][5])
     finally:
         dist.destroy_process_group()
 
 
-def test_ep_all_to_all_matches_single_process_oracle():
-    world = 2
-    port = 29500 + (os.getpid() % 2000)
+@pytest.mark.parametrize("world,scenario", [(2, "uniform"), (4, "uniform"), (4, "skewed")])
+def test_ep_all_to_all_matches_single_process_oracle(world, scenario):
+    port = 29500 + (os.getpid() % 2000) + world
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, ret, scenario), nprocs=world, join=True)
         for r in range(world):
-            ok1, ok2, ok3, sent = ret[r]
-            assert ok1, f"rank {r}: EP result != full-expert oracle"
-            assert ok2, f"rank {r}: all-to-all path != masked all-gather path"
-            assert ok3, f"rank {r}: dispatch plan sends duplicate (token, rank) rows"
-            assert sent > 0
+            x = ret[r]
+            assert all(x["pred"]), f"rank {r}: EP result != full-expert oracle (reference predicate)"
+            assert all(x["bound"]), f"rank {r}: EP result outside the stated rounding bound"
+            assert x["same"], f"rank {r}: exact-count and fixed-capacity exchanges differ"
+            assert x["alt"], f"rank {r}: all-to-all path != masked all-gather path"
+            assert x["plan"], f"rank {r}: dispatch plan is not 'each (token, rank) once, ascending'"
+            assert x["overflow"] == 0
+            assert x["cap_stats"]["rows_sent"] == world * x["cap_stats"]["capacity"]
+        if scenario == "skewed":
+            assert ret[1]["received"] == [0] and ret[2]["received"] == [0], "ranks 1 and 2 own no routed expert: zero rows"
+            assert ret[0]["received"][0] > 0 and ret[3]["received"][0] > 0
+        else:
+            assert all(ret[r]["stats"]["rows_sent"] > 0 for r in range(world))

@@ -2,7 +2,7 @@
 
 NOT the reference's numerics: /root/reference/bench_moe.py:113-130 is W8A16.  So these tests hold the kernels to an oracle
 of THEIR arithmetic (oracle/moe_a8.py: quantise exactly as the kernels do, then exact sums) at a stated tolerance --
-relative RMS < 1e-2 (measured ~3e-3: the bf16 roundings of ic2 / out plus rare rounding-boundary flips of the fp8
+relative RMS < 5e-3 (measured ~1e-3: the bf16 roundings of ic2 / out plus rare rounding-boundary flips of the fp8
 quantisation) -- and only REPORT how far the mode is from the reference's W8A16 oracle (about 4-5 % relative RMS; it does
 not meet the reference predicate and is therefore never a default).  The quantisation pass itself is bit-exact.
 """
@@ -16,7 +16,7 @@ from oracle import c_oracle, moe_a8
 
 pytestmark = pytest.mark.gpu
 
-A8_TOL = 1e-2
+A8_TOL = 5e-3
 
 
 @pytest.fixture(scope="module")

@@ -50,7 +50,13 @@ def main():
     t_plain = timed(lambda: local(a, tw, ids))
     t_ep = timed(lambda: ep(a, tw, ids))
     ref, out = local(a, tw, ids), ep(a, tw, ids)
-    print(f"plain fused_experts {t_plain:.3f} ms, EP step (world 1) {t_ep:.3f} ms, same bits: {torch.equal(ref, out)}", flush=True)
+    print(f"plain fused_experts {t_plain:.3f} ms, EP step (world 1) {t_ep:.3f} ms (+{(t_ep / t_plain - 1) * 100:.1f} %), "
+          f"same bits: {torch.equal(ref, out)}", flush=True)
+    for cf in (None, 1.0):
+        epp = ExpertParallelMoE(E, local, capacity_factor=cf, profile=True)
+        t = timed(lambda: epp(a, tw, ids))
+        print(f"  split mode {'exact counts' if cf is None else 'capacity 1.0'}: {t:.3f} ms (+{(t / t_plain - 1) * 100:.1f} %), phases "
+              f"{epp.phase_ms()}, same bits: {torch.equal(ref, epp(a, tw, ids))}, {epp.last_stats}", flush=True)
     # two steps in flight on two streams (what bench.py does for N > 1): step i+1's plan, gathers and dispatch overlap
     # step i's experts; every step owns its stream's workspace
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
