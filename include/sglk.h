@@ -142,7 +142,9 @@ enum {
     SGLK_PATH_TAILS_SPLIT = 0x2000,   /* tail tiles on the mid kernel */
     SGLK_PATH_TAILS_AUX = 0x4000,     /* ... on the caller's aux stream */
     SGLK_PATH_PERSIST_G1 = 0x8000,    /* GEMM-1 launched persistent (one workgroup per CU, tile loop + tickets) */
-    SGLK_PATH_PERSIST_G2 = 0x10000    /* GEMM-2 launched persistent */
+    SGLK_PATH_PERSIST_G2 = 0x10000,   /* GEMM-2 launched persistent */
+    SGLK_PATH_ROUTE_ALIGN = 0x20000,  /* sglk_moe_block: router + align ran as one launch */
+    SGLK_PATH_SHARED_FOLDED = 0x40000 /* sglk_moe_block: routed combine folded into the shared expert's last launch */
 };
 
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
@@ -150,6 +152,40 @@ size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32
 size_t sglk_fused_experts_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype,
                                              int32_t flags);
 int sglk_fused_experts(const sglk_fused_experts_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * moe_block                   router -> routed experts (-> shared expert) as ONE call
+ * The reference harness makes these calls one after the other (/root/reference/test_moe.py:57-92:
+ * grouped_topk_cpu then fused_experts_cpu; /root/reference/test_shared_experts.py:34-40,68: shared_expert_cpu with the
+ * routed output as `fused_experts_out`); this entry point computes the same thing with fewer launches:
+ *   topk_weights, topk_ids = grouped_topk(gating, topk, renormalize, num_expert_group, topk_group [, correction_bias])
+ *   routed = fused_experts(hidden, w1, w2, topk_weights, topk_ids)
+ *   out    = shared_N > 0 ? shared_mlp(hidden; shared_w1, shared_w2) + routed * routed_scaling_factor : routed
+ * - decode batches (M <= 16, E <= 256): router and the routing sort are ONE launch; ids / weights are bit-identical to
+ *   sglk_grouped_topk's and are returned in experts.topk_weights / experts.topk_ids (OUTPUT buffers [M][topk] here);
+ * - shared expert, fp8 packed weights, decode sizes: its last launch sums the routed slots itself (no combine launch, no
+ *   [M][K] round trip).  `routed` is then never rounded to bf16, so the result differs from the three separate calls by
+ *   that one rounding (it is the more accurate one); other shapes run the separate kernels on a scratch buffer.
+ * experts.out is the final output; experts.workspace must hold sglk_moe_block_workspace_bytes().
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    sglk_fused_experts_args experts;
+    const void* gating;           /* [M][E] router logits */
+    int64_t gating_stride;
+    int32_t gating_type;          /* 0 bf16, 1 f16, 2 f32 */
+    const void* correction_bias;  /* [E] same type as gating, or NULL (softmax scoring) */
+    int32_t renormalize, num_expert_group, topk_group;
+    int32_t shared_N;             /* shared expert's intermediate size; 0 = no shared expert */
+    const void* shared_w1;        /* [2*shared_N][K] */
+    const void* shared_w2;        /* [K][shared_N] */
+    const float* shared_w1_scale;
+    const float* shared_w2_scale;
+    int32_t shared_packed;
+    float routed_scaling_factor;
+} sglk_moe_block_args;
+size_t sglk_moe_block_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype, int32_t flags,
+                                      int32_t shared_N);
+int sglk_moe_block(const sglk_moe_block_args* args, void* stream);
 
 /* First stage of the opt-in a8 mode (SGLK_MOE_FP8_ACT), exported so that it can be checked bit for bit on its own:
  * x [rows][cols] bf16 -> q [rows][cols] e4m3 + scale [rows][scale_stride] E8M0 bytes, one per 128-wide block

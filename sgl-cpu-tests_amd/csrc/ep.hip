@@ -3,8 +3,7 @@
 //
 //   ep_plan : for every destination rank d, the tokens that route at least one slot to an expert of d, in ascending token
 //             order (a stable compaction, so the exchange is deterministic): counts[d] and pos[m][d] = index of token m
-//             inside the segment for d (-1: not sent).  One workgroup of 1024 threads walks contiguous token chunks
-//             (count, block scan, assign): M * topk ids are read twice, 1 MB at M = 16384.
+//             inside the segment for d (-1: not sent).  One launch of ceil(M / 1024) workgroups.
 //   ep_pack : one payload row per (token, destination): [K bf16 | topk local ids i32 | topk routing weights f32], ids
 //             rewritten to the destination's numbering and -1 elsewhere -- rows and routing travel in ONE all-to-all.
 //             Segment of destination d starts at seg_start[d] rows (exact mode: exclusive sum of counts; capacity mode:
@@ -15,13 +14,16 @@ namespace sglk {
 
 constexpr int kEpMaxRanks = 16;
 
+// Workgroup b plans tokens [1024 b, 1024 b + 1024).  It needs the number of earlier tokens per destination; instead of a
+// chained scan over workgroups it simply RE-COUNTS them (all 1024 threads over the ids of tokens [0, 1024 b): at most 512 KB
+// from L2 at M = 16384): one launch, no inter-workgroup synchronisation, deterministic.
 __global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ ids, int M, int topk, int E, int G, int epr,
                                                        int capacity, int* __restrict__ counts, int* __restrict__ seg_start,
                                                        int* __restrict__ pos, int* __restrict__ overflow) {
     __shared__ int wave_tot[16][kEpMaxRanks];
+    __shared__ int base_s[kEpMaxRanks];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (M + 1023) / 1024;
-    const int m0 = tid * chunk, m1 = min(M, m0 + chunk);
+    const int first = blockIdx.x * 1024;
     auto mask_of = [&](int m) {
         unsigned mask = 0;
         for (int j = 0; j < topk; ++j) {
@@ -30,66 +32,77 @@ __global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ i
         }
         return mask;
     };
+    // ---- tokens before this workgroup's range, per destination ------------------------------------------------------------
     int cnt[kEpMaxRanks];
 #pragma unroll
     for (int d = 0; d < kEpMaxRanks; ++d) cnt[d] = 0;
-    for (int m = m0; m < m1; ++m) {
+#pragma unroll 4
+    for (int m = tid; m < first; m += 1024) {
         const unsigned mask = mask_of(m);
 #pragma unroll
         for (int d = 0; d < kEpMaxRanks; ++d) cnt[d] += (mask >> d) & 1u;
     }
-    // exclusive scan over threads, per rank: inside the wave by shuffles, across the 16 waves through LDS
-    int excl[kEpMaxRanks];
 #pragma unroll
     for (int d = 0; d < kEpMaxRanks; ++d) {
         int v = cnt[d];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) wave_tot[wave][d] = v;
+    }
+    __syncthreads();
+    if (tid < kEpMaxRanks) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_tot[w][tid];
+        base_s[tid] = t;
+    }
+    __syncthreads();
+    // ---- own token: exclusive scan over the workgroup's 1024 tokens, per destination -----------------------------------------
+    const int m = first + tid;
+    const unsigned mask = m < M ? mask_of(m) : 0u;
+    int excl[kEpMaxRanks];
+#pragma unroll
+    for (int d = 0; d < kEpMaxRanks; ++d) {
+        const int mine = (mask >> d) & 1u;
+        int v = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(v, o);
             if (lane >= o) v += u;
         }
-        excl[d] = v - cnt[d];
-        if (lane == 63) wave_tot[wave][d] = v;
+        excl[d] = v - mine;
+        if (lane == 63) wave_tot[wave][d] = v;   // safe: the reads of the first use finished before the second barrier above
     }
     __syncthreads();
+    const bool last = blockIdx.x == gridDim.x - 1;
+    int run = 0;   // last workgroup, thread 0: exclusive sum of the totals = segment starts of the exact mode
 #pragma unroll
     for (int d = 0; d < kEpMaxRanks; ++d) {
-        int before = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int t = wave_tot[w][d];
-            before += w < wave ? t : 0;
-            total += t;
-        }
-        excl[d] += before;
-        if (tid == 0 && d < G) {
-            counts[d] = total;
-            if (capacity > 0 && total > capacity) atomicOr(overflow, 1 << d);
-        }
-    }
-    if (tid == 0) {   // segment starts: exact mode = exclusive sum of the counts, capacity mode = d * capacity
-        int run = 0;
-        for (int d = 0; d < G; ++d) {
-            int total = 0;
-            for (int w = 0; w < 16; ++w) total += wave_tot[w][d];
-            seg_start[d] = capacity > 0 ? d * capacity : run;
-            run += total;
-        }
-        seg_start[G] = capacity > 0 ? G * capacity : run;
-    }
-    for (int m = m0; m < m1; ++m) {
-        const unsigned mask = mask_of(m);
-#pragma unroll
-        for (int d = 0; d < kEpMaxRanks; ++d) {
-            if (d < G) {
+        if (d < G) {
+            int before = 0, total = 0;
+            for (int w = 0; w < 16; ++w) {
+                const int t = wave_tot[w][d];
+                before += w < wave ? t : 0;
+                total += t;
+            }
+            const int b0 = base_s[d];
+            if (m < M) {
                 int p = -1;
                 if ((mask >> d) & 1u) {
-                    p = excl[d]++;
-                    if (capacity > 0 && p >= capacity) p = -1;   // dropped (flagged in *overflow)
+                    p = b0 + before + excl[d];
+                    if (capacity > 0 && p >= capacity) p = -1;   // dropped (flagged in *overflow by the last workgroup)
                 }
                 pos[(int64_t)m * G + d] = p;
             }
+            if (last && tid == 0) {
+                const int all = b0 + total;
+                counts[d] = all;
+                seg_start[d] = capacity > 0 ? d * capacity : run;
+                run += all;
+                if (capacity > 0 && all > capacity) atomicOr(overflow, 1 << d);
+            }
         }
     }
+    if (last && tid == 0) seg_start[G] = capacity > 0 ? G * capacity : run;
 }
 
 // one wave per token: copy its row + routing to every destination segment it belongs to
@@ -139,8 +152,8 @@ extern "C" int sglk_ep_plan(const int32_t* topk_ids, int32_t M, int32_t topk, in
     SGLK_REQUIRE(counts && seg_start && pos && overflow && (M == 0 || topk_ids), SGLK_ERR_INVALID, "ep_plan: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(overflow, 0, sizeof(int), s) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "ep_plan: memset failed");
-    hipLaunchKernelGGL(ep_plan_kernel, dim3(1), dim3(1024), 0, s, topk_ids, M, topk, E, G, E / G, capacity, counts, seg_start, pos,
-                       overflow);
+    hipLaunchKernelGGL(ep_plan_kernel, dim3((unsigned)(M > 0 ? ceil_div(M, 1024) : 1)), dim3(1024), 0, s, topk_ids, M, topk, E, G, E / G,
+                       capacity, counts, seg_start, pos, overflow);
     SGLK_CHECK_LAUNCH("ep_plan");
     return SGLK_OK;
 }

@@ -152,7 +152,22 @@ extern "C" size_t sglk_fused_experts_workspace_bytes_ex(int32_t M, int32_t N, in
     return plan_workspace(M, N, K, E, topk, wtype, flags).total;
 }
 
-extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream) {
+namespace {
+// router inputs of sglk_moe_block: topk_weights / topk_ids of the experts' args are then OUTPUTS of the call
+struct RouteArgs {
+    const void* gating;
+    int64_t gating_stride;
+    int gating_type;
+    const void* bias;
+    int renormalize, G, topk_group;
+};
+int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const RouteArgs* route, const sglk_shared_expert_args* shared);
+}  // namespace
+
+extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream) { return fused_experts_impl(a, stream, nullptr, nullptr); }
+
+namespace {
+int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const RouteArgs* route, const sglk_shared_expert_args* shared) {
     SGLK_REQUIRE(a, SGLK_ERR_INVALID, "fused_experts: null args");
     const int M = a->M, N = a->N, K = a->K, E = a->E, topk = a->topk;
     SGLK_REQUIRE(M >= 0 && N > 0 && K > 0 && E > 0 && topk > 0, SGLK_ERR_INVALID,
@@ -236,7 +251,23 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
     int* tile_info_b = (int*)(ws + w.tile_info_b);
     int* num_tiles_b = (int*)(ws + w.num_tiles_b);
     mark(0);
-    int rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
+    int rc = SGLK_OK;
+    bool routed_and_aligned = false;
+    if (route) {
+        // router: grouped top-k writes topk_weights / topk_ids; decode-size batches do it in the SAME launch as the align
+        if (route_align_ok(M, E, topk) && !split_tails && !knobs().no_block_fold) {
+            rc = launch_route_align(route->gating, route->gating_stride, route->gating_type, route->bias, (float*)a->topk_weights,
+                                    (int32_t*)a->topk_ids, M, E, topk, route->renormalize, route->G, route->topk_group, tile_m,
+                                    sorted_slot, expert_off, tile_info, num_tiles, s);
+            routed_and_aligned = true;
+        } else {
+            rc = sglk_grouped_topk(route->gating, route->gating_stride, route->gating_type, route->bias, (float*)a->topk_weights,
+                                   (int32_t*)a->topk_ids, M, E, topk, route->renormalize, route->G, route->topk_group, stream);
+        }
+        if (rc != SGLK_OK) return rc;
+    }
+    if (!routed_and_aligned)
+        rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
                                     w.sorted_slot - w.align_ws, stream);
     if (rc != SGLK_OK) return rc;
@@ -276,6 +307,9 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         q1.out_stride = N;
         q1.out_s = ic1s;
         q1.out_s_stride = ic1s_stride;
+#ifdef SGLK_DEV_ABLATE
+        if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
+#endif
         rc = launch_moe_gemm_a8(MODE_GATE_UP, q1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
@@ -300,6 +334,9 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         q2.out = ic2;
         q2.out_stride = K;
         q2.topk_weights = a->topk_weights;
+#ifdef SGLK_DEV_ABLATE
+        if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
+#endif
         rc = launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
@@ -689,7 +726,14 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
         mark(3);
     }
 
-    rc = launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
+    if (shared) {
+        // moe block: the shared expert's last launch sums the routed slots itself (x routed_scaling_factor) -- no combine
+        // launch, no [M][K] round trip of the routed output
+        const MoeSlotAddend moe{ic2, a->topk_ids, topk, E};
+        rc = shared_expert_impl(shared, stream, &moe);
+    } else {
+        rc = launch_moe_combine(ic2, a->topk_ids, (uint16_t*)a->out, a->out_stride, M, K, E, topk, s);
+    }
     mark(4);
     if (a->path_taken) {
         int path = (tile_m & SGLK_PATH_TILE_MASK) | (a8 ? SGLK_PATH_FP8_ACT : 0);
@@ -698,9 +742,68 @@ extern "C" int sglk_fused_experts(const sglk_fused_experts_args* a, void* stream
             if (moe_gemm_fp8w_256i_is_persistent(K, (int64_t)max_tiles * (N / 128))) path |= SGLK_PATH_PERSIST_G1;
             if (moe_gemm_fp8w_256i_is_persistent(N, (int64_t)max_tiles * (K / 256))) path |= SGLK_PATH_PERSIST_G2;
         }
-        *a->path_taken = path;
+        *a->path_taken = path | (routed_and_aligned ? SGLK_PATH_ROUTE_ALIGN : 0) | (shared ? SGLK_PATH_SHARED_FOLDED : 0);
     }
     return rc;
+}
+}  // namespace
+
+extern "C" size_t sglk_moe_block_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype,
+                                                 int32_t flags, int32_t shared_N) {
+    if (M < 0 || N <= 0 || K <= 0 || E <= 0 || topk <= 0) return 0;
+    size_t t = align_up(plan_workspace(M, N, K, E, topk, wtype, flags).total, 256);
+    if (shared_N > 0) t += align_up(sglk_shared_expert_workspace_bytes(M, shared_N, K, wtype), 256) + align_up((size_t)M * K * 2, 256);
+    return t;
+}
+
+extern "C" int sglk_moe_block(const sglk_moe_block_args* b, void* stream) {
+    SGLK_REQUIRE(b, SGLK_ERR_INVALID, "moe_block: null args");
+    const sglk_fused_experts_args& ex0 = b->experts;
+    SGLK_REQUIRE(b->gating && (ex0.M == 0 || (ex0.topk_weights && ex0.topk_ids)), SGLK_ERR_INVALID, "moe_block: null pointer");
+    SGLK_REQUIRE(b->gating_type >= 0 && b->gating_type <= 2 && b->gating_stride >= ex0.E, SGLK_ERR_INVALID, "moe_block: gating");
+    const int M = ex0.M, N = ex0.N, K = ex0.K, E = ex0.E, topk = ex0.topk;
+    SGLK_REQUIRE(M >= 0 && N > 0 && K > 0 && E > 0 && topk > 0, SGLK_ERR_INVALID, "moe_block: bad sizes");
+    const size_t ws_ex = align_up(plan_workspace(M, N, K, E, topk, ex0.wtype, ex0.flags).total, 256);
+    const size_t ws_sh = b->shared_N > 0 ? align_up(sglk_shared_expert_workspace_bytes(M, b->shared_N, K, ex0.wtype), 256) : 0;
+    const size_t ws_tmp = b->shared_N > 0 ? align_up((size_t)M * K * 2, 256) : 0;
+    SGLK_REQUIRE(ex0.workspace && ex0.workspace_bytes >= ws_ex + ws_sh + ws_tmp, SGLK_ERR_WORKSPACE,
+                 "moe_block: workspace %zu < required %zu", ex0.workspace_bytes, ws_ex + ws_sh + ws_tmp);
+    const RouteArgs route{b->gating, b->gating_stride, b->gating_type, b->correction_bias, b->renormalize, b->num_expert_group,
+                          b->topk_group};
+    sglk_fused_experts_args ex = ex0;
+    ex.workspace_bytes = ws_ex;
+    if (b->shared_N <= 0) return fused_experts_impl(&ex, stream, &route, nullptr);
+    SGLK_REQUIRE(b->shared_w1 && b->shared_w2, SGLK_ERR_INVALID, "moe_block: shared expert weights missing");
+    unsigned char* wsb = (unsigned char*)ex0.workspace;
+    sglk_shared_expert_args sh{};
+    sh.hidden = ex0.hidden;
+    sh.hidden_stride = ex0.hidden_stride;
+    sh.out = ex0.out;
+    sh.out_stride = ex0.out_stride;
+    sh.w1 = b->shared_w1;
+    sh.w2 = b->shared_w2;
+    sh.w1_scale = b->shared_w1_scale;
+    sh.w2_scale = b->shared_w2_scale;
+    sh.routed_scaling_factor = b->routed_scaling_factor;
+    sh.M = M;
+    sh.N = b->shared_N;
+    sh.K = K;
+    sh.wtype = ex0.wtype;
+    sh.packed = b->shared_packed;
+    sh.block_n = ex0.block_n;
+    sh.block_k = ex0.block_k;
+    sh.workspace = wsb + ws_ex;
+    sh.workspace_bytes = ws_sh;
+    if (M > 0 && shared_expert_can_fold(&sh) && !knobs().no_block_fold) return fused_experts_impl(&ex, stream, &route, &sh);
+    // the shared expert's path for this shape has no slot addend: routed experts into a scratch [M][K], then the plain call
+    uint16_t* tmp = (uint16_t*)(wsb + ws_ex + ws_sh);
+    ex.out = tmp;
+    ex.out_stride = K;
+    int rc = fused_experts_impl(&ex, stream, &route, nullptr);
+    if (rc != SGLK_OK) return rc;
+    sh.fused_out = tmp;
+    sh.fused_out_stride = K;
+    return shared_expert_impl(&sh, stream, nullptr);
 }
 
 extern "C" void* sglk_stage_timer_create(int32_t max_calls) {

@@ -128,13 +128,29 @@ extern "C" size_t sglk_shared_expert_workspace_bytes(int32_t M, int32_t N, int32
     return plan_dense(M, N, K, true, wtype == SGLK_W_INT8).total;
 }
 
-extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream) {
+namespace sglk {
+// the decode-size fp8 path of shared_expert_impl (two split-K passes of the weight-streaming kernel), the one whose last
+// launch can take the routed experts' combine as a slot addend
+bool shared_expert_can_fold(const sglk_shared_expert_args* a) {
+    return a->wtype == SGLK_W_FP8_E4M3 && (a->packed & 3) == 3 && a->block_k == 128 && a->block_n > 0 && a->block_n % 16 == 0 &&
+           a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 && !knobs().force_generic && a->N % 128 == 0 &&
+           !tuned_dense_ok(a->M, 2 * a->N, a->K, a->wtype, 1, a->block_n, a->block_k, a->hidden, a->hidden_stride) &&
+           mid_dense_ksplit(a->M, 2 * a->N, a->K) >= 1 && mid_dense_ksplit(a->M, a->K, a->N) >= 1;
+}
+
+int shared_expert_impl(const sglk_shared_expert_args* a, void* stream, const MoeSlotAddend* moe);
+}  // namespace sglk
+
+extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream) { return sglk::shared_expert_impl(a, stream, nullptr); }
+
+int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, const MoeSlotAddend* moe) {
     SGLK_REQUIRE(a, SGLK_ERR_INVALID, "shared_expert: null args");
     const int M = a->M, N = a->N, K = a->K;
     SGLK_REQUIRE(M >= 0 && N > 0 && K > 0, SGLK_ERR_INVALID, "shared_expert: bad sizes M=%d N=%d K=%d", M, N, K);
     SGLK_REQUIRE(a->w1 && a->w2 && a->workspace, SGLK_ERR_INVALID, "shared_expert: null pointer");
-    SGLK_REQUIRE(M == 0 || (a->hidden && a->out && a->fused_out), SGLK_ERR_INVALID, "shared_expert: null pointer");
-    SGLK_REQUIRE(a->hidden_stride >= K && a->out_stride >= K && a->fused_out_stride >= K, SGLK_ERR_INVALID,
+    SGLK_REQUIRE(M == 0 || (a->hidden && a->out && (a->fused_out || moe)), SGLK_ERR_INVALID, "shared_expert: null pointer");
+    SGLK_REQUIRE(!moe || shared_expert_can_fold(a), SGLK_ERR_INVALID, "shared_expert: this path cannot fold the routed combine");
+    SGLK_REQUIRE(a->hidden_stride >= K && a->out_stride >= K && (moe || a->fused_out_stride >= K), SGLK_ERR_INVALID,
                  "shared_expert: row stride < K");
     int rc = check_weight("shared_expert", a->wtype, a->packed & 1, 2 * N, K, a->w1_scale, a->block_n, a->block_k);
     if (rc != SGLK_OK) return rc;
@@ -217,9 +233,16 @@ extern "C" int sglk_shared_expert(const sglk_shared_expert_args* a, void* stream
             r.out = a->out;
             r.out_type = SGLK_OUT_BF16;
             r.out_stride = a->out_stride;
-            r.addend = a->fused_out;
-            r.addend_stride = a->fused_out_stride;
             r.addend_scale = a->routed_scaling_factor;
+            if (moe) {
+                r.moe_ic2 = moe->ic2;
+                r.moe_ids = moe->topk_ids;
+                r.moe_topk = moe->topk;
+                r.moe_E = moe->E;
+            } else {
+                r.addend = a->fused_out;
+                r.addend_stride = a->fused_out_stride;
+            }
             return launch_splitk_reduce(r, s);
         }
     }

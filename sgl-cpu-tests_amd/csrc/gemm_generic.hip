@@ -315,6 +315,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GenericGemmPar
         for (int k = 0; k < p.ksplit; ++k) v += p.partial[((int64_t)k * p.split_rows + r) * p.n_out + c];
         if (p.bias) v += p.bias[c];
         if (p.addend) v += bf16_bits_to_f32(reinterpret_cast<const unsigned short*>(p.addend)[r * p.addend_stride + c]) * p.addend_scale;
+        if (p.moe_ic2) {   // routed experts' combine, folded in: fp32 sum over the valid slots in slot order
+            float sum = 0.f;
+            for (int j = 0; j < p.moe_topk; ++j) {
+                const int e = p.moe_ids[r * p.moe_topk + j];
+                if (e >= 0 && e < p.moe_E) sum += bf16_bits_to_f32(p.moe_ic2[(r * p.moe_topk + j) * p.n_out + c]);
+            }
+            v += sum * p.addend_scale;
+        }
         if (p.out_type == SGLK_OUT_F32) reinterpret_cast<float*>(p.out)[r * p.out_stride + c] = v;
         else if (p.out_type == SGLK_OUT_F16) reinterpret_cast<_Float16*>(p.out)[r * p.out_stride + c] = (_Float16)v;
         else reinterpret_cast<unsigned short*>(p.out)[r * p.out_stride + c] = f32_to_bf16_bits(v);

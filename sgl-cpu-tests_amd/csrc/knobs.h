@@ -23,6 +23,7 @@ struct Knobs {
     int max_wgs = 0;             // SGLK_MAX_WGS: cap on the persistent launches' workgroups (tests: forces many tiles per
                                  //               workgroup on small problems); 0 = one per CU
     int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
+    bool no_block_fold = false;  // SGLK_NO_BLOCK_FOLD: sglk_moe_block runs router / align / combine / shared expert unfused (A/B)
     int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)
     int rescale_ablate = 0;      // SGLK_RESCALE (SGLK_DEV_ABLATE builds only)
     unsigned long long dbg_ptr = 0;   // SGLK_DBG_PTR (SGLK_DEV_ABLATE builds only)

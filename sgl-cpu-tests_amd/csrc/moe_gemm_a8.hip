@@ -156,6 +156,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
         if (jt >= xl) return;
         L = xs + jt;
     }
+#ifdef SGLK_DEV_ABLATE
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#define SGLK_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[32 * L + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SGLK_STAMP(i) do { } while (0)
+#endif
     const int mtile = L / p.n_tiles, ntile = L - mtile * p.n_tiles;
     const int4 ti = p.tile_info[mtile];
     const int e = __builtin_amdgcn_readfirstlane(ti.x);
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
 
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
     i32x8 fa[2], fb[4];
+    float nsc[2] = {0.f, 0.f};
     auto ld_a = [&](i32x8& dst, int rt, int buf) {
         const unsigned char* b = smem + (buf * kStage + woff0);
         const i32x4 lo = *reinterpret_cast<const i32x4*>(b + rt * kRt1);
@@ -336,6 +343,14 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
 
     const bool active = wm * 128 < rows;
     int buf = 0;
+#ifdef SGLK_DEV_ABLATE
+    if (p.dbg && tid == 0) {
+        p.dbg[32 * L + 18] = rt_entry;
+        p.dbg[32 * L + 22] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        p.dbg[32 * L + 23] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
+#endif
+    SGLK_STAMP(19);
     // Stage t (ring slot `buf`); every flag is a literal at the call site.
     //   first   : first stage of a K block -- the scales switch; with resc_hi accumulators 6, 7 are rescaled (slots 0, 1)
     //   bound   : closing stage of a K block that is not the last -- rescale accumulators 0..5 in slots 2..7
@@ -343,25 +358,31 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
     //             have landed, later ones stay in flight) + lgkmcnt(0) + barrier; the fragments of stage t+1 are read after it
     //   dma     : stage t+4 exists: its four pieces go into THIS stage's ring slot, which nobody reads after the sync point
     //   own     : read this stage's row tile 1 / token tile 3 in slot 0 (false only for stage 0, preloaded)
-    auto stage = [&](int t, bool first, bool bound, int wait, bool dma, bool resc_hi, bool own) {
+    //   pre     : first stage of a K block that is not the last: the NEXT block's scales (weight scale of both row tiles, the
+    //             four token scale bytes) are read from the LDS tables here, a whole stage before `bound` consumes them
+    auto stage = [&](int t, bool first, bool bound, int wait, bool dma, bool resc_hi, bool own, bool pre) {
         int nbuf = buf + 1;
         if (nbuf == kRing) nbuf = 0;
-        if (bound) {
-            const int kb = (t + 1) >> 1;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float nm;
-                split_scale(sc[wpiece0[rt] * kMaxKB + kb], ea_next[rt], nm);
-                ratio[rt] = uniform_f32(mant[rt] * __builtin_amdgcn_rcpf(nm));
-                mant[rt] = nm;
-            }
-            ld_xs(kb, xsv_next);
-        }
-        if (first) {
+        if (first) {   // this block's scales (read one block ago) become current ...
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) ea[rt] = ea_next[rt];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) xsv[tt] = xsv_next[tt];
+        }
+        if (pre) {     // ... BEFORE the next block's are requested into the same registers
+            const int kb = (t >> 1) + 1;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) nsc[rt] = sc[wpiece0[rt] * kMaxKB + kb];
+            ld_xs(kb, xsv_next);
+        }
+        if (bound) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float nm;
+                split_scale(nsc[rt], ea_next[rt], nm);
+                ratio[rt] = uniform_f32(mant[rt] * __builtin_amdgcn_rcpf(nm));
+                mant[rt] = nm;
+            }
         }
         mma(0);
         SGLK_FENCE();
@@ -427,22 +448,22 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
         SGLK_FENCE();
         int t = 0;
         if (kblocks > 2) {
-            stage(0, true, false, 8, true, false, false);
-            stage(1, false, true, 8, true, false, true);
+            stage(0, true, false, 8, true, false, false, true);
+            stage(1, false, true, 8, true, false, true, false);
             for (t = 2; t + 4 < T; t += 2) {
-                stage(t, true, false, 8, true, true, true);
-                stage(t + 1, false, true, 8, true, true, true);
+                stage(t, true, false, 8, true, true, true, true);
+                stage(t + 1, false, true, 8, true, true, true, false);
             }
             // t == T - 4
-            stage(t, true, false, 8, false, true, true);
-            stage(t + 1, false, true, 4, false, true, true);
-            stage(t + 2, true, false, 0, false, true, true);
-            stage(t + 3, false, false, -1, false, true, true);
+            stage(t, true, false, 8, false, true, true, true);
+            stage(t + 1, false, true, 4, false, true, true, false);
+            stage(t + 2, true, false, 0, false, true, true, false);
+            stage(t + 3, false, false, -1, false, true, true, false);
         } else {   // kblocks == 2: stages 0..3, no stage 4
-            stage(0, true, false, 8, false, false, false);
-            stage(1, false, true, 4, false, false, true);
-            stage(2, true, false, 0, false, true, true);
-            stage(3, false, false, -1, false, true, true);
+            stage(0, true, false, 8, false, false, false, true);
+            stage(1, false, true, 4, false, false, true, false);
+            stage(2, true, false, 0, false, true, true, false);
+            stage(3, false, false, -1, false, true, true, false);
         }
     } else {
         int t = 0;
@@ -453,10 +474,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
         idle_stage(t + 3, -1, false);
     }
 #undef SGLK_FENCE
+    SGLK_STAMP(20);
 
     // ---- epilogue (ring dead).  32x32 accumulator: lane = token column (l & 31); register i = weight row
     //      (i & 3) + 8 * (i >> 2) + 4 * (l >> 5) of the row tile ----
     __syncthreads();
+    SGLK_STAMP(25);
     int tidv = tid;
     asm volatile("" : "+v"(tidv));
     const int r32e = tidv & 31, he = (tidv >> 5) & 1;
@@ -498,7 +521,9 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
                 *reinterpret_cast<int*>(rowp + chunk * 16 + (pos & 15)) = d;
             }
         }
+        SGLK_STAMP(26);
         __syncthreads();
+        SGLK_STAMP(27);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = it * 512 + tidv;
@@ -531,7 +556,9 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
                 }
             }
         }
+        SGLK_STAMP(26);
         __syncthreads();
+        SGLK_STAMP(27);
         uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -543,6 +570,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
             }
         }
     }
+#ifdef SGLK_DEV_ABLATE
+    if (p.dbg && tid == 0) {
+        p.dbg[32 * L + 21] = __builtin_amdgcn_s_memrealtime();   // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[32 * L + 24] = __builtin_amdgcn_s_memrealtime();   // stores acknowledged
+    }
+#endif
 }
 
 }  // namespace ga8

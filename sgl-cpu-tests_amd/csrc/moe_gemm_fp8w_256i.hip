@@ -20,6 +20,8 @@
 //     stored with 16-byte accesses (ic1 rows are contiguous positions, ic2 rows are scattered by slot).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "knobs.h"
 #include "moe_internal.h"
 
@@ -30,6 +32,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace g256i {
 
+#ifdef SGLK_NO_TAIL_SKIP   // A/B build: tail tiles run every MFMA like full tiles
+constexpr bool kTailSkip = false;
+#else
+constexpr bool kTailSkip = true;
+#endif
 constexpr int kBM = 256;
 constexpr int kStageX = kBM * 128;        // 32 KiB
 constexpr int kStageW = 16 * 1024;        // 16 KiB: 16 packed 16x64 fp8 tiles
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         float sc_reg[2];      // scale-table entries sc[tid], sc[tid + 512]  (sc[piece * 64 + kb])
     };
     const int kblocks_ = p.C >> 7;
-    auto fetch_meta = [&](int Lq, Meta& m) {
+    auto fetch_meta = [&](int Lq, Meta& m) __attribute__((always_inline)) {
         SGLK_SPLIT_L(Lq, mt, nt);
         (void)mt;
         const int e_ = __builtin_amdgcn_readfirstlane(m.ti.x), pos0_ = __builtin_amdgcn_readfirstlane(m.ti.y);
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     const int T = ctiles;
 
     // workgroup's 16 weight row-tiles: GATE_UP = 8 gate + 8 up, DOWN = 16 consecutive
-    auto piece_row16 = [&](int piece) {
+    auto piece_row16 = [&](int piece) __attribute__((always_inline)) {
         if (MODE == MODE_GATE_UP) return (piece < 8) ? ntile * 8 + piece : (p.n_half >> 4) + ntile * 8 + (piece - 8);
         return ntile * 16 + piece;
     };
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // one of the wave's six 1-KiB LDS-DMA pieces of stage kt (0..3: X rows, 4..5: packed W tiles).  The pieces of a
     // stage are issued ONE PER MFMA GROUP, never as a burst: a buffer_load...lds costs the issuing wave 60-180 cycles,
     // which hides behind the MFMAs already queued on the matrix pipe but stalls the wave when six come back to back.
-    auto issue_piece = [&](int kt, int buf, int i) {
+    auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {
         if ((RESCALE & 64) && kt > 2) return;   // bit 6: timing ablation, no LDS-DMA in the steady state
         unsigned char* sx = smem + buf * kStage;
         if (i < 4)
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lptr_t)(sx + kStageX + (wave * 2 + i - 4) * 1024), 16,
                                                      wsrc[i - 4], kt * 1024, 0, 0);
     };
-    auto issue_stage = [&](int kt, int buf) {
+    auto issue_stage = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) issue_piece(kt, buf, i);
     };
@@ -276,10 +283,10 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         wbase[rt] = (wpiece0[rt] + (r32 >> 4)) * 1024 + (r32 & 15) * 16;
     }
     // k-step ks: octet o = 2ks + h -> slot group (o&3), half (o>>2)
-    auto woff = [&](int rt, int ks) { return wbase[rt] + (((2 * ks + h) & 3) * 16) * 16 + ((2 * ks + h) >> 2) * 8; };
+    auto woff = [&](int rt, int ks) __attribute__((always_inline)) { return wbase[rt] + (((2 * ks + h) & 3) * 16) * 16 + ((2 * ks + h) >> 2) * 8; };
     // token tile tt (32 tokens): row = wm*NTT*32 + tt*32 + r32, chunk 2ks + h, swizzled by (row>>1)&7
     const int xrow0 = wm * (NTT * 32) + r32;
-    auto xoff = [&](int tt, int ks) {
+    auto xoff = [&](int tt, int ks) __attribute__((always_inline)) {
         const int row = xrow0 + tt * 32;
         return row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4);
     };
@@ -332,40 +339,48 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // Registers: converted weights wf[parity][rt], token fragments xf[parity][tt] (parity = k-step & 1), raw octets
     // wraw[rt] of the k-step being converted.
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // token tiles (32 tokens) of this wave that hold at least one row: NTT except in an expert's last (tail) tile
+    int nta = (rows - wm * (NTT * 32) + 31) >> 5;
+    nta = __builtin_amdgcn_readfirstlane(nta < 0 ? 0 : (nta > NTT ? NTT : nta));
     u32x4 wfw[2][NRT], xf[2][NTT];
     u32x2 wraw[NRT];
     // MFMA slot s of a k-step -> (row tile, token tile); consecutive slots alternate accumulators
-    auto slot_rt = [&](int s2) { return NRT == 2 ? (s2 >> 1) & 1 : s2 >> 1; };
-    auto slot_tt = [&](int s2) { return NRT == 2 ? (s2 & 1) + 2 * (s2 >> 2) : s2 & 1; };
-    auto ld_w = [&](int rt, int fbuf, int ks) {
+    auto slot_rt = [&](int s2) __attribute__((always_inline)) { return NRT == 2 ? (s2 >> 1) & 1 : s2 >> 1; };
+    auto slot_tt = [&](int s2) __attribute__((always_inline)) { return NRT == 2 ? (s2 & 1) + 2 * (s2 >> 2) : s2 & 1; };
+    auto ld_w = [&](int rt, int fbuf, int ks) __attribute__((always_inline)) {
         wraw[rt] = *reinterpret_cast<const u32x2*>(smem + fbuf * kStage + kStageX + woff(rt, ks));
     };
-    auto ld_x = [&](int par, int tt, int fbuf, int ks) {
+    // chk (a literal at every call site): the tile is a TAIL tile whose last rows end inside this wave's token range -- token
+    // tiles (32 tokens) that hold no row at all are skipped: no fragment read, no MFMA, no rescale (nta = tiles with rows)
+    auto ld_x = [&](int par, int tt, int fbuf, int ks, bool chk) __attribute__((always_inline)) {
+        if (chk && tt >= nta) return;
         if ((RESCALE & 16) && (ks | tt)) return;   // timing ablation: one X read per stage
         xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
     // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
-    auto cvt2 = [&](int par, int rt, int half, float sc2) {
+    auto cvt2 = [&](int par, int rt, int half, float sc2) __attribute__((always_inline)) {
         const unsigned src = half ? wraw[rt][1] : wraw[rt][0];
         if (RESCALE & 8) { wfw[par][rt][2 * half] = src; wfw[par][rt][2 * half + 1] = src; return; }   // timing ablation: no conversion
         wfw[par][rt][2 * half] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, false));
         wfw[par][rt][2 * half + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, true));
     };
-    auto mma = [&](int par, int s2) {
+    auto mma = [&](int par, int s2, bool chk) __attribute__((always_inline)) {
         const int rt = slot_rt(s2), tt = slot_tt(s2);
+        if (chk && tt >= nta) return;
         acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfw[par][rt]),
                                                               __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
     };
-    auto rescale = [&](int a) {   // accumulator of MFMA slot a into units of the next K block's mantissa
+    auto rescale = [&](int a, bool chk) __attribute__((always_inline)) {   // accumulator of MFMA slot a into units of the next K block's mantissa
         if (RESCALE & 4) return;   // timing ablation: no rescale
         const int rt = slot_rt(a), tt = slot_tt(a);
+        if (chk && tt >= nta) return;
         // one plain v_mul_f32 per register: beside MFMAs a packed v_pk_mul_f32 costs the wave ~3x the issue time of the
         // two scalar multiplies it replaces (MI355X_MICROARCH.md, cycle constants), and the vector form of this
         // statement is always lowered to the packed instruction
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][i]) : "s"(ratio[rt]));
     };
-    auto sync_point = [&](bool wait6) {
+    auto sync_point = [&](bool wait6) __attribute__((always_inline)) {
         if (wait6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (RESCALE & 1024) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // timing ablation: NO barrier (racy)
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     //   resc_lo / resc_hi : K-block boundary -- rescale accumulators 0..4 in slots 3..7 / accumulators 5..7 in slots 0..2
     //   next_pow2 : the conversions of this k-step belong to the next K block
     auto kstep = [&](int ks, bool fetch, bool sync, bool wait6, int dma_a, int dma_b, int dma_stage, int dma_buf,
-                     bool resc_lo, bool resc_hi, bool next_pow2) {
+                     bool resc_lo, bool resc_hi, bool next_pow2, bool chk) __attribute__((always_inline)) {
         const int par = ks & 1, npar = par ^ 1;
         int nbuf = buf + 1;
         if (nbuf == kRing) nbuf = 0;
@@ -389,12 +404,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         // feed slices of the NEXT k-step (fks of fbuf), by slot:
         //   NRT = 2:  0: W0+X0   1: W1+X1   2: X2   3: X3        4..7: one half row tile converted per slot
         //   NRT = 4:  0: W0+X0   1: W1+X1   2: W2   3: W3        4..7: one whole row tile converted per slot
-        auto feed_reads = [&](int s2) {
+        auto feed_reads = [&](int s2) __attribute__((always_inline)) {
             if (!fetch) return;
             if (s2 < NRT) ld_w(s2, fbuf, fks);
-            if (s2 < NTT) ld_x(npar, s2, fbuf, fks);
+            if (s2 < NTT) ld_x(npar, s2, fbuf, fks, chk);
         };
-        auto feed_cvt = [&](int s2) {   // s2 in 4..7
+        auto feed_cvt = [&](int s2) __attribute__((always_inline)) {   // s2 in 4..7
             if (!fetch) return;
             if (NRT == 2) {
                 const int rt = (s2 - 4) >> 1, half = (s2 - 4) & 1;
@@ -407,55 +422,55 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
             }
         };
         // slot 0
-        mma(par, 0);
+        mma(par, 0, chk);
         SGLK_FENCE();
         if (sync) {
-            mma(par, 1);
+            mma(par, 1, chk);
             SGLK_FENCE();
             sync_point(wait6);
             feed_reads(0);
             feed_reads(1);
-            if (resc_hi) { rescale(5); }
+            if (resc_hi) { rescale(5, chk); }
             SGLK_FENCE();
         } else {
             feed_reads(0);
-            if (resc_hi) rescale(5);
+            if (resc_hi) rescale(5, chk);
             SGLK_FENCE();
             // slot 1
-            mma(par, 1);
+            mma(par, 1, chk);
             SGLK_FENCE();
             feed_reads(1);
-            if (resc_hi) rescale(6);
+            if (resc_hi) rescale(6, chk);
             SGLK_FENCE();
         }
         // slot 2
-        mma(par, 2);
+        mma(par, 2, chk);
         SGLK_FENCE();
         feed_reads(2);
-        if (resc_hi) rescale(7);
+        if (resc_hi) rescale(7, chk);
         SGLK_FENCE();
         // slot 3
-        mma(par, 3);
+        mma(par, 3, chk);
         SGLK_FENCE();
         feed_reads(3);
         if (kDmaSlotA == 3 && dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
-        if (resc_lo) rescale(0);
+        if (resc_lo) rescale(0, chk);
         SGLK_FENCE();
         // slots 4..7
 #pragma unroll
         for (int s2 = 4; s2 < 8; ++s2) {
-            mma(par, s2);
+            mma(par, s2, chk);
             SGLK_FENCE();
             feed_cvt(s2);
             if (s2 == kDmaSlotA && dma_a >= 0) issue_piece(dma_stage, dma_buf, dma_a);
             if (s2 == 7 && dma_b >= 0) issue_piece(dma_stage, dma_buf, dma_b);
-            if (resc_lo) rescale(s2 - 3);
+            if (resc_lo) rescale(s2 - 3, chk);
             SGLK_FENCE();
         }
     };
     // stage t.  first / closing: first / second stage of a 128-wide K block.  dma_mid: pieces 2..5 of stage t+2 go out in
     // k-steps 0,1; dma_tail: pieces 0,1 of stage t+3 in k-step 3 (into this stage's own buffer, free after S_t).
-    auto stage = [&](int t, bool first, bool closing, bool has_next, bool wait6, bool dma_mid, bool dma_tail, bool boundary) {
+    auto stage = [&](int t, bool first, bool closing, bool has_next, bool wait6, bool dma_mid, bool dma_tail, bool boundary, bool chk) __attribute__((always_inline)) {
         int pbuf = buf - 1;
         if (pbuf < 0) pbuf = kRing - 1;
         if (closing && boundary) {
@@ -472,15 +487,15 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) pow2[rt] = pow2_next[rt];
         }
-        kstep(0, true, false, false, dma_mid ? 2 : -1, dma_mid ? 3 : -1, t + 2, pbuf, false, first, false);
-        kstep(1, true, false, false, dma_mid ? 4 : -1, dma_mid ? 5 : -1, t + 2, pbuf, false, false, false);
-        kstep(2, true, false, false, -1, -1, 0, 0, false, false, false);
+        kstep(0, true, false, false, dma_mid ? 2 : -1, dma_mid ? 3 : -1, t + 2, pbuf, false, first, false, chk);
+        kstep(1, true, false, false, dma_mid ? 4 : -1, dma_mid ? 5 : -1, t + 2, pbuf, false, false, false, chk);
+        kstep(2, true, false, false, -1, -1, 0, 0, false, false, false, chk);
         kstep(3, has_next, has_next, wait6, dma_tail ? 0 : -1, dma_tail ? 1 : -1, t + 3, buf, closing && boundary, false,
-              closing && boundary);
+              closing && boundary, chk);
         buf = (buf + 1 == kRing) ? 0 : buf + 1;
     };
     // waves without rows (tail tiles): keep the DMA pieces and the sync points, skip the math
-    auto idle_stage = [&](int t, bool has_next, bool wait6, bool dma_mid, bool dma_tail) {
+    auto idle_stage = [&](int t, bool has_next, bool wait6, bool dma_mid, bool dma_tail) __attribute__((always_inline)) {
         int pbuf = buf - 1;
         if (pbuf < 0) pbuf = kRing - 1;
         if (dma_mid) {
@@ -499,28 +514,36 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #endif
     // T = 2 * kblocks >= 4 stages.  Steady state while stage t+3 exists; the last two K blocks are peeled so that the
     // DMA / wait flags stay literals.
-    if (active) {
+    // the main loop exists twice: for full tiles (every MFMA unconditional) and for tail tiles whose wave has fewer than NTT
+    // token tiles with rows (a wave-uniform test in front of every token tile's read / MFMA / rescale)
+    auto main_loop = [&](auto chk_c) __attribute__((always_inline)) {
+        constexpr bool chk = decltype(chk_c)::value;
         // operands of (stage 0, k-step 0)
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) ld_w(rt, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) ld_x(0, tt, 0, 0);
+        for (int tt = 0; tt < NTT; ++tt) ld_x(0, tt, 0, 0, chk);
 #pragma unroll
         for (int rt = 0; rt < NRT; ++rt) { cvt2(0, rt, 0, pow2[rt]); cvt2(0, rt, 1, pow2[rt]); }
         SGLK_FENCE();
         int t = 0;
         for (; t + 4 < T; t += 2) {
-            stage(t, true, false, true, true, true, true, true);
-            stage(t + 1, false, true, true, true, true, true, true);
+            stage(t, true, false, true, true, true, true, true, chk);
+            stage(t + 1, false, true, true, true, true, true, true, chk);
         }
         // t == T - 4 (when T >= 4): stages T-4 .. T-1
         if (t + 3 < T) {
-            stage(t, true, false, true, true, true, true, true);          // T-4: pieces 2..5 of T-2, pieces 0,1 of T-1
-            stage(t + 1, false, true, true, true, true, false, true);     // T-3: pieces 2..5 of T-1
+            stage(t, true, false, true, true, true, true, true, chk);          // T-4: pieces 2..5 of T-2, pieces 0,1 of T-1
+            stage(t + 1, false, true, true, true, true, false, true, chk);     // T-3: pieces 2..5 of T-1
             t += 2;
         }
-        stage(t, true, false, true, false, false, false, true);           // T-2: waits for all of T-1
-        stage(t + 1, false, true, false, false, false, false, false);     // T-1: nothing follows
+        stage(t, true, false, true, false, false, false, true, chk);           // T-2: waits for all of T-1
+        stage(t + 1, false, true, false, false, false, false, false, chk);     // T-1: nothing follows
+    };
+    if (active && (nta == NTT || !kTailSkip)) {
+        main_loop(std::false_type{});
+    } else if (active) {
+        main_loop(std::true_type{});
     } else {
         int t = 0;
         for (; t + 4 < T; t += 2) {

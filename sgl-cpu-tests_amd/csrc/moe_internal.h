@@ -72,6 +72,7 @@ struct A8GemmParams {
     uint8_t* out_s;               // GATE_UP: ic1 scale bytes [position][out_s_stride]
     int out_s_stride;
     const float* topk_weights;    // DOWN
+    unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
 int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
 // hidden bf16 [rows][cols] -> e4m3 (packed-tile k order) + one E8M0 byte per 128-wide block
@@ -168,6 +169,11 @@ struct GenericGemmParams {
     // applies bias / addend / the output cast.  ksplit <= 1: off.
     int ksplit, split_stages, split_rows;
     float* partial;
+    // split-K reduce only (moe block): instead of `addend`, add addend_scale * sum over the valid routing slots j (ascending)
+    // of moe_ic2[(row * moe_topk + j)][n_out] -- the routed experts' top-k combine folded into the shared expert's last launch
+    const uint16_t* moe_ic2;
+    const int32_t* moe_ids;
+    int moe_topk, moe_E;
 };
 
 // int8 W8A8 fused_experts at small / mid batch sizes, weight-streaming (gemm_i8_mid.hip); grouped modes only
@@ -241,6 +247,21 @@ int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipSt
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,
                            int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, int32_t tail_max,
                            int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream);
+
+// the routed experts' per-slot rows, to be summed (valid slots, ascending) and scaled inside another kernel's epilogue
+struct MoeSlotAddend {
+    const uint16_t* ic2;          // [M * topk][K] bf16, slot order
+    const int32_t* topk_ids;      // [M][topk]; ids outside [0, E) contribute nothing
+    int topk, E;
+};
+bool shared_expert_can_fold(const sglk_shared_expert_args* a);
+int shared_expert_impl(const sglk_shared_expert_args* a, void* stream, const MoeSlotAddend* moe);
+
+// router (grouped top-k, softmax or sigmoid + bias) + moe_align in ONE launch for decode-size batches (topk.hip)
+bool route_align_ok(int M, int E, int topk);
+int launch_route_align(const void* gating, int64_t gating_stride, int gating_type, const void* bias, float* topk_weights,
+                       int32_t* topk_ids, int M, int E, int topk, int renormalize, int G, int topk_group, int tile_m,
+                       int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, hipStream_t s);
 
 // out[m] = sum over valid slots j (ascending) of ic2[m*topk + j], fp32 sum, one bf16 rounding
 int launch_moe_combine(const uint16_t* ic2, const int32_t* topk_ids, uint16_t* out, int64_t out_stride, int M,

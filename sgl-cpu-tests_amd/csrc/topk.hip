@@ -13,11 +13,17 @@
 // oracle bit for bit (oracle/routing.py ranks equal fp32 scores by logit, then index -- a refinement of the open tie rule).
 // Sigmoid + bias variant: the ranking key sigmoid(x) + bias is a rounded quantity; ids equal the oracle's except on
 // genuine near-ties of that key (asserted as such in tests/test_rows_topk_gpu.py).  Output order: descending key.
-#include "sglk_common.h"
+#include "moe_align_small.h"
+#include "moe_internal.h"
 
 namespace sglk {
 
 constexpr int kTopkMaxE = 1024;   // experts per token: 16 per lane
+// router + align in one workgroup: ONE token per wave.  More tokens per wave lose: the sixteen waves of the single workgroup
+// all reduce through the one CU's cross-lane (ds_bpermute) path -- measured 14 us per extra round of 16 tokens (M = 64: 196 vs
+// 140 us for the whole block), while the stand-alone router spreads its tokens over many CUs.
+constexpr int kRouteAlignMaxTokens = 16;
+constexpr int kRouteAlignMaxSlots = 1024;
 constexpr int kPerLane = kTopkMaxE / 64;
 
 SGLK_DEV float wave_max(float v) {
@@ -48,25 +54,17 @@ SGLK_DEV float ld_gate(const void* p, int64_t idx) {
     return bf16_bits_to_f32(b);
 }
 
-template <int GT, bool BIASED>
-__global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restrict__ gating, int64_t g_stride,
-                                                           const void* __restrict__ bias, float* __restrict__ out_w,
-                                                           int* __restrict__ out_ids, int M, int E, int topk,
-                                                           int renormalize, int G, int topk_group) {
-    __shared__ float s_choice[4][kTopkMaxE];
-    __shared__ float s_gscore[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
-    if (m >= M) return;   // whole wave; no block-level barrier is used below
-    float* choice_l = s_choice[wave];
-    float* gscore_l = s_gscore[wave];
+// Routing of ONE token by one wave.  PL = experts per lane (E <= 64 * PL).  choice_l [64 * PL floats] and gscore_l are this
+// wave's LDS scratch.  Lanes < topk return their pick in (my_w, my_id), `wsum` is the sum of the picked scores on all lanes.
+template <int GT, bool BIASED, int PL>
+SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride, const void* __restrict__ bias, int m, int E,
+                              int topk, int G, int topk_group, float* choice_l, int lane, float& my_w, int& my_id, float& wsum) {
     const int per_group = E / G;
-
     // ---- scores ---------------------------------------------------------------------------------------------------
-    float score[kPerLane], choice[kPerLane];
+    float score[PL], choice[PL];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < kPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
         const int e = j * 64 + lane;
         score[j] = e < E ? ld_gate<GT>(gating, (int64_t)m * g_stride + e) : -INFINITY;
         choice[j] = score[j];   // softmax variant: the ranking key is the logit itself
@@ -76,16 +74,16 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         mx = wave_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) {
+        for (int j = 0; j < PL; ++j) {
             score[j] = (j * 64 + lane < E) ? expf(score[j] - mx) : 0.f;
             sum += score[j];
         }
         sum = wave_sum(sum);
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) score[j] /= sum;
+        for (int j = 0; j < PL; ++j) score[j] /= sum;
     } else {
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) {
+        for (int j = 0; j < PL; ++j) {
             const int e = j * 64 + lane;
             if (e < E) {
                 score[j] = 1.0f / (1.0f + expf(-score[j]));
@@ -97,7 +95,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         }
     }
 #pragma unroll
-    for (int j = 0; j < kPerLane; ++j)
+    for (int j = 0; j < PL; ++j)
         if (j * 64 + lane < E) choice_l[j * 64 + lane] = choice[j];
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -123,21 +121,21 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         if (i < G) gmask |= 1ull << i;
     }
     // ---- topk experts among the selected groups --------------------------------------------------------------------------
-    float masked[kPerLane];
+    float masked[PL];
 #pragma unroll
-    for (int j = 0; j < kPerLane; ++j) {
+    for (int j = 0; j < PL; ++j) {
         const int e = j * 64 + lane;
         const bool in = e < E && ((gmask >> (e / per_group)) & 1ull);
         masked[j] = in ? choice[j] : -INFINITY;
     }
-    float wsum = 0.f;
-    float my_w = 0.f;
-    int my_id = 0;
+    wsum = 0.f;
+    my_w = 0.f;
+    my_id = 0;
     for (int r = 0; r < topk; ++r) {
         float bv = -INFINITY;
         int bi = 1 << 20;
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) {
+        for (int j = 0; j < PL; ++j) {
             const int e = j * 64 + lane;
             // only live candidates (> -inf); equal values -> lower index
             if (e < E && masked[j] > -INFINITY && (masked[j] > bv || (masked[j] == bv && e < bi))) { bv = masked[j]; bi = e; }
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         if (i >= E) {   // all remaining candidates are -inf: take the lowest index still marked "not taken"
             int cand = 1 << 20;
 #pragma unroll
-            for (int j = 0; j < kPerLane; ++j) {
+            for (int j = 0; j < PL; ++j) {
                 const int e = j * 64 + lane;
                 if (e < E && masked[j] == -INFINITY && choice[j] != INFINITY && e < cand) cand = e;   // choice==INF marks taken
             }
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         }
         // owner lane retires the pick and supplies its (unbiased) score
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) {
+        for (int j = 0; j < PL; ++j) {
             if (j * 64 + lane == i) {
                 const bool was_selected_group = masked[j] != -INFINITY;
                 w_sel = (BIASED || was_selected_group) ? score[j] : 0.f;
@@ -172,15 +170,89 @@ __global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restric
         wsum += w_sel;
         if (lane == r) { my_w = w_sel; my_id = i; }
     }
+}
+
+template <int GT, bool BIASED>
+__global__ __launch_bounds__(256) void grouped_topk_kernel(const void* __restrict__ gating, int64_t g_stride,
+                                                           const void* __restrict__ bias, float* __restrict__ out_w,
+                                                           int* __restrict__ out_ids, int M, int E, int topk,
+                                                           int renormalize, int G, int topk_group) {
+    __shared__ float s_choice[4][kTopkMaxE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;   // whole wave; no block-level barrier is used below
+    float my_w, wsum;
+    int my_id;
+    route_one_token<GT, BIASED, kPerLane>(gating, g_stride, bias, m, E, topk, G, topk_group, s_choice[wave], lane, my_w, my_id, wsum);
     if (lane < topk) {
         out_ids[(int64_t)m * topk + lane] = my_id;
         out_w[(int64_t)m * topk + lane] = renormalize ? my_w / wsum : my_w;
     }
 }
 
+
+// ---- router + align in ONE launch (no reference counterpart: the reference harness calls
+//      grouped_topk_cpu and fused_experts_cpu one after the other, /root/reference/test_moe.py:57-92) -------------------------
+// One workgroup of 16 waves: wave w routes tokens w, w + 16, ... exactly as grouped_topk_kernel does (same device function:
+// ids and weights are bit-identical to the stand-alone operator), keeps the ids in LDS, and after one barrier the whole
+// workgroup runs the small stable counting sort + tile table on them (moe_align_small.h).  For decode batches of up to 16
+// tokens: saves the launch boundary between the two kernels and the global round trip of the ids (3.6 us of 47.6 at M = 1).
+template <int GT, bool BIASED>
+__global__ __launch_bounds__(1024) void route_align_kernel(const void* __restrict__ gating, int64_t g_stride,
+                                                           const void* __restrict__ bias, float* __restrict__ out_w,
+                                                           int* __restrict__ out_ids, int M, int E, int topk, int renormalize,
+                                                           int G, int topk_group, int nbits, int tile_m, int max_tiles,
+                                                           int* __restrict__ sorted_slot, int* __restrict__ expert_off,
+                                                           int* __restrict__ tile_info, int* __restrict__ num_tiles) {
+    __shared__ float s_choice[16][kSmallMaxE];
+    __shared__ int s_ids[kRouteAlignMaxSlots];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int m = wave; m < M; m += 16) {
+        float my_w, wsum;
+        int my_id;
+        route_one_token<GT, BIASED, kSmallMaxE / 64>(gating, g_stride, bias, m, E, topk, G, topk_group, s_choice[wave], lane, my_w,
+                                                     my_id, wsum);
+        if (lane < topk) {
+            out_ids[(int64_t)m * topk + lane] = my_id;
+            out_w[(int64_t)m * topk + lane] = renormalize ? my_w / wsum : my_w;
+            s_ids[m * topk + lane] = my_id;
+        }
+    }
+    __syncthreads();
+    moe_align_small_body(s_ids, M * topk, E, nbits, tile_m, max_tiles, sorted_slot, expert_off, tile_info, num_tiles);
+}
+
 }  // namespace sglk
 
 using namespace sglk;
+
+namespace sglk {
+bool route_align_ok(int M, int E, int topk) { return M >= 1 && M <= kRouteAlignMaxTokens && E <= kSmallMaxE && M * topk <= kRouteAlignMaxSlots; }
+
+int launch_route_align(const void* gating, int64_t gating_stride, int gating_type, const void* bias, float* topk_weights,
+                       int32_t* topk_ids, int M, int E, int topk, int renormalize, int G, int topk_group, int tile_m,
+                       int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, hipStream_t s) {
+    if (!route_align_ok(M, E, topk)) SGLK_FAIL(SGLK_ERR_SHAPE, "route_align: M=%d E=%d topk=%d outside the one-workgroup range", M, E, topk);
+    int nbits = 0;
+    while ((1 << nbits) < E) ++nbits;
+    const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
+#define RA_LAUNCH(GT, B)                                                                                                \
+    hipLaunchKernelGGL((route_align_kernel<GT, B>), dim3(1), dim3(1024), 0, s, gating, gating_stride, bias, topk_weights, topk_ids, \
+                       M, E, topk, renormalize, G, topk_group, nbits, tile_m, max_tiles, sorted_slot, expert_off, tile_info, num_tiles)
+    if (bias) {
+        if (gating_type == 0) RA_LAUNCH(0, true);
+        else if (gating_type == 1) RA_LAUNCH(1, true);
+        else RA_LAUNCH(2, true);
+    } else {
+        if (gating_type == 0) RA_LAUNCH(0, false);
+        else if (gating_type == 1) RA_LAUNCH(1, false);
+        else RA_LAUNCH(2, false);
+    }
+#undef RA_LAUNCH
+    SGLK_CHECK_LAUNCH("route_align");
+    return SGLK_OK;
+}
+}  // namespace sglk
 
 extern "C" int sglk_grouped_topk(const void* gating, int64_t gating_stride, int32_t gating_type, const void* bias,
                                  float* topk_weights, int32_t* topk_ids, int32_t M, int32_t E, int32_t topk,

@@ -9,6 +9,7 @@ W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2
 MOE_FP8_ACT = 1                      # sglk_fused_experts_args.flags
 PATH_TILE_MASK, PATH_FP8_ACT, PATH_TAILS_SPLIT, PATH_TAILS_AUX, PATH_PERSIST_G1, PATH_PERSIST_G2 = (
     0x3ff, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000)
+PATH_ROUTE_ALIGN, PATH_SHARED_FOLDED = 0x20000, 0x40000
 
 
 class FusedExpertsArgs(ctypes.Structure):
@@ -26,6 +27,20 @@ class FusedExpertsArgs(ctypes.Structure):
         ("stage_timer", ctypes.c_void_p),
         ("aux_stream", ctypes.c_void_p), ("aux_events", ctypes.c_void_p * 2),
         ("flags", ctypes.c_int32), ("path_taken", ctypes.POINTER(ctypes.c_int32)),
+    ]
+
+
+class MoeBlockArgs(ctypes.Structure):
+    """Mirror of `sglk_moe_block_args`."""
+    _fields_ = [
+        ("experts", FusedExpertsArgs),
+        ("gating", ctypes.c_void_p), ("gating_stride", ctypes.c_int64), ("gating_type", ctypes.c_int32),
+        ("correction_bias", ctypes.c_void_p),
+        ("renormalize", ctypes.c_int32), ("num_expert_group", ctypes.c_int32), ("topk_group", ctypes.c_int32),
+        ("shared_N", ctypes.c_int32),
+        ("shared_w1", ctypes.c_void_p), ("shared_w2", ctypes.c_void_p),
+        ("shared_w1_scale", ctypes.c_void_p), ("shared_w2_scale", ctypes.c_void_p),
+        ("shared_packed", ctypes.c_int32), ("routed_scaling_factor", ctypes.c_float),
     ]
 
 
@@ -119,6 +134,8 @@ _SIGNATURES = {
     "sglk_fused_experts_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 6),
     "sglk_fused_experts_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int32] * 7),
     "sglk_fused_experts": (ctypes.c_int, [ctypes.POINTER(FusedExpertsArgs), ctypes.c_void_p]),
+    "sglk_moe_block_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 8),
+    "sglk_moe_block": (ctypes.c_int, [ctypes.POINTER(MoeBlockArgs), ctypes.c_void_p]),
     "sglk_quant_fp8_block128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_moe_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),

@@ -102,7 +102,14 @@ def _staged(fn):
                     return a
             return out.cpu()
         if isinstance(out, tuple):
-            return tuple(o.cpu() if isinstance(o, torch.Tensor) else o for o in out)
+            def back(o):
+                if not isinstance(o, torch.Tensor):
+                    return o
+                for a, m in zip(args, moved):
+                    if isinstance(a, torch.Tensor) and o is m:
+                        return a          # an in-place result: hand back the caller's own (updated) tensor
+                return o.cpu()
+            return tuple(back(o) for o in out)
         return out
     return wrapper
 
@@ -304,6 +311,107 @@ def _mut_inplace(a, args):
     return a is args[0] and bool(args[5])
 
 
+# ------------------------------------------------------------------------------------------------------
+# fused_moe_block      router -> routed experts (-> shared expert) in one call.  The reference harness
+#                      makes the calls separately: grouped_topk_cpu + fused_experts_cpu (/root/reference/test_moe.py:57-92),
+#                      shared_expert_cpu on the routed output (/root/reference/test_shared_experts.py:34-40,68)
+# ------------------------------------------------------------------------------------------------------
+_DEF.define(
+    "fused_moe_block(Tensor(a!) hidden_states, Tensor router_logits, Tensor w1, Tensor w2, int topk, bool renormalize, "
+    "int num_expert_group, int topk_group, Tensor? correction_bias, bool inplace, bool use_int8_w8a8, bool use_fp8_w8a16, "
+    "Tensor? w1_scale, Tensor? w2_scale, int[]? block_size, bool is_vnni, Tensor? shared_w1, Tensor? shared_w2, "
+    "Tensor? shared_w1_scale, Tensor? shared_w2_scale, float routed_scaling_factor) -> (Tensor, Tensor, Tensor)")
+
+_GATING_TYPE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def fused_moe_block(hidden_states, router_logits, w1, w2, topk, renormalize, num_expert_group, topk_group, correction_bias,
+                    inplace, use_int8_w8a8, use_fp8_w8a16, w1_scale, w2_scale, block_size, is_vnni, shared_w1, shared_w2,
+                    shared_w1_scale, shared_w2_scale, routed_scaling_factor):
+    """-> (out [M,K] bf16, topk_weights [M,topk] f32, topk_ids [M,topk] i32)"""
+    if use_int8_w8a8 and use_fp8_w8a16:
+        raise RuntimeError("fused_moe_block: use_int8_w8a8 and use_fp8_w8a16 are mutually exclusive")
+    if hidden_states.dim() != 2 or w1.dim() != 3 or w2.dim() != 3 or hidden_states.dtype != torch.bfloat16:
+        raise RuntimeError("fused_moe_block: expect bf16 hidden [M,K], w1 [E,2N,K], w2 [E,K,N]")
+    M, K = hidden_states.shape
+    E, N2, K1 = w1.shape
+    N = N2 // 2
+    if K1 != K or tuple(w2.shape) != (E, K, N) or tuple(router_logits.shape) != (M, E):
+        raise RuntimeError("fused_moe_block: shape mismatch")
+    if router_logits.dtype not in _GATING_TYPE:
+        raise RuntimeError(f"fused_moe_block: router_logits dtype {router_logits.dtype}")
+    wdtype = torch.int8 if use_int8_w8a8 else (torch.float8_e4m3fn if use_fp8_w8a16 else torch.bfloat16)
+    if w1.dtype != wdtype or w2.dtype != wdtype:
+        raise RuntimeError(f"fused_moe_block: weights must be {wdtype} for this mode")
+    hs = hidden_states if hidden_states.stride(1) == 1 else hidden_states.contiguous()
+    gating = router_logits if router_logits.stride(1) == 1 else router_logits.contiguous()
+    bias = None
+    if correction_bias is not None:
+        bias = correction_bias.to(gating.dtype).contiguous()
+    w1, w2 = w1.contiguous(), w2.contiguous()
+    bn = bk = 0
+    if use_fp8_w8a16:
+        if block_size is None or len(block_size) != 2:
+            raise RuntimeError("fused_moe_block: fp8 needs block_size = [block_n, block_k]")
+        bn, bk = int(block_size[0]), int(block_size[1])
+    if wdtype != torch.bfloat16:
+        if w1_scale is None or w2_scale is None:
+            raise RuntimeError("fused_moe_block: quantised modes need w1_scale and w2_scale")
+        w1_scale, w2_scale = _f32c(w1_scale), _f32c(w2_scale)
+    shared_N = 0
+    if shared_w1 is not None:
+        if shared_w2 is None or shared_w1.dim() != 2 or shared_w1.shape[1] != K or shared_w1.dtype != wdtype:
+            raise RuntimeError("fused_moe_block: expect shared_w1 [2*Ns,K], shared_w2 [K,Ns] of the experts' dtype")
+        shared_N = shared_w1.shape[0] // 2
+        if tuple(shared_w2.shape) != (K, shared_N):
+            raise RuntimeError("fused_moe_block: shared_w2 shape")
+        shared_w1, shared_w2 = shared_w1.contiguous(), shared_w2.contiguous()
+        if wdtype != torch.bfloat16:
+            if shared_w1_scale is None or shared_w2_scale is None:
+                raise RuntimeError("fused_moe_block: the shared expert needs its scales")
+            shared_w1_scale, shared_w2_scale = _f32c(shared_w1_scale), _f32c(shared_w2_scale)
+    out = hs if (inplace and hs is hidden_states) else torch.empty_like(hs)
+    tw = torch.empty(M, topk, dtype=torch.float32, device=hs.device)
+    ids = torch.empty(M, topk, dtype=torch.int32, device=hs.device)
+    L = _lib.lib()
+    wtype = _WTYPE[wdtype]
+    flags = _lib.MOE_FP8_ACT if (_fp8_act and use_fp8_w8a16) else 0
+    ws_bytes = L.sglk_moe_block_workspace_bytes(M, N, K, E, topk, wtype, flags, shared_N)
+    ws = _workspace(ws_bytes, hs.device)
+    path = ctypes.c_int32(0)
+    ex = _lib.FusedExpertsArgs(
+        hidden=hs.data_ptr(), hidden_stride=hs.stride(0), out=out.data_ptr(), out_stride=out.stride(0),
+        w1=w1.data_ptr(), w2=w2.data_ptr(),
+        w1_scale=w1_scale.data_ptr() if w1_scale is not None else None,
+        w2_scale=w2_scale.data_ptr() if w2_scale is not None else None,
+        topk_weights=tw.data_ptr(), topk_ids=ids.data_ptr(), M=M, N=N, K=K, E=E, topk=topk, wtype=wtype,
+        packed=_packed_bits(is_vnni, (2 * N, K), (K, N), wdtype), block_n=bn, block_k=bk,
+        workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=_stage_timer,
+        aux_stream=None, aux_events=(ctypes.c_void_p * 2)(), flags=flags, path_taken=ctypes.pointer(path))
+    args = _lib.MoeBlockArgs(
+        experts=ex, gating=gating.data_ptr(), gating_stride=gating.stride(0), gating_type=_GATING_TYPE[gating.dtype],
+        correction_bias=bias.data_ptr() if bias is not None else None,
+        renormalize=int(bool(renormalize)), num_expert_group=int(num_expert_group), topk_group=int(topk_group),
+        shared_N=shared_N,
+        shared_w1=shared_w1.data_ptr() if shared_N else None, shared_w2=shared_w2.data_ptr() if shared_N else None,
+        shared_w1_scale=shared_w1_scale.data_ptr() if (shared_N and shared_w1_scale is not None) else None,
+        shared_w2_scale=shared_w2_scale.data_ptr() if (shared_N and shared_w2_scale is not None) else None,
+        shared_packed=_packed_bits(is_vnni, (2 * shared_N, K), (K, shared_N), wdtype) if shared_N else 0,
+        routed_scaling_factor=float(routed_scaling_factor))
+    _lib.check(L.sglk_moe_block(ctypes.byref(args), _stream(hs)), "fused_moe_block")
+    global last_path
+    last_path = path.value
+    if inplace and out is not hidden_states:
+        hidden_states.copy_(out)
+        out = hidden_states
+    return out, tw, ids
+
+
+def _mut_block(a, args):
+    return a is args[0] and bool(args[9])
+
+
+_impl("fused_moe_block", fused_moe_block, _mut_block)
 _impl("fused_experts_cpu", fused_experts_cpu, _mut_inplace)
 _impl("fused_experts_cpu.method", fused_experts_cpu_method, _mut_inplace)
 

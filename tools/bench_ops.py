@@ -245,6 +245,65 @@ def bench_shared():
              tflops=round(6 * M * N * K / ms / 1e9, 2))
 
 
+def bench_block():
+    """fused_moe_block (router + align in one launch, routed combine folded into the shared expert's last launch) against the
+    separate operator calls of the reference flow, decode sizes, device time per call from hipGraph replays."""
+    K, N, E, topk, Ns = 2048, 768, 128, 8, 2048
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda *sh: (torch.randn(*sh, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
+    w1p, w2p = ops.convert_weight_packed(mk(E, 2 * N, K)), ops.convert_weight_packed(mk(E, K, N))
+    s1p, s2p = ops.convert_weight_packed(mk(2 * Ns, K)), ops.convert_weight_packed(mk(K, Ns))
+    w1s = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3
+    w2s = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
+    s1s = torch.randn(2 * Ns // 128, K // 128, device="cuda", generator=g) * 1e-3
+    s2s = torch.randn(K // 128, Ns // 128, device="cuda", generator=g) * 1e-3
+
+    def graph_ms(fn, reps=200):
+        fn(); fn()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(10):
+                fn()
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps // 10):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (reps // 10 * 10)
+
+    for shared in (False, True):
+        for M in (1, 4, 16, 64):
+            a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+            logits = torch.randn(M, E, device="cuda", generator=g).bfloat16()
+            sh = (s1p, s2p, s1s, s2s) if shared else (None, None, None, None)
+
+            def fused():
+                return ops.fused_moe_block(a, logits, w1p, w2p, topk, True, 1, 1, None, False, False, True, w1s, w2s, [128, 128],
+                                           True, *sh, 1.0)
+
+            def separate():
+                tw, ids = ops.grouped_topk_cpu(a, logits, topk, True, 1, 1, 0, None, None)
+                out = ops.fused_experts_cpu(a, w1p, w2p, tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
+                if shared:
+                    out = ops.shared_expert_cpu(a, s1p, s2p, out, 1.0, False, False, True, s1s, s2s, [128, 128], None, None, True)
+                return out
+
+            t_f, t_s = graph_ms(fused), graph_ms(separate)
+            emit(op="fused_moe_block", M=M, shared_expert=shared, ms_block=round(t_f, 4), ms_separate_calls=round(t_s, 4),
+                 saved_us=round((t_s - t_f) * 1e3, 2),
+                 note="Qwen3-30B-A3B expert dims fp8 (+ a 2048-wide fp8 shared expert); hipGraph replay, device time per call")
+
+
 def bench_mxfp4():
     """mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py): W4A16, weights expanded to bf16 in the loader.  Small M is bound
     by the weight bytes (N*K/2 + scales), large M by the bf16 matrix cores; bmm_cpu rides along (test_bmm_fp8.py:131-132)."""
@@ -366,7 +425,7 @@ def bench_rows():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_offload": bench_moe_offload, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "shared": bench_shared, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
+    table = {"moe": bench_moe, "moe_literal": bench_moe_literal, "moe_offload": bench_moe_offload, "moe_int8": bench_moe_int8, "gemm": bench_gemm, "shared": bench_shared, "block": bench_block, "mxfp4": bench_mxfp4, "attn": bench_attn, "absorb": bench_absorb, "rows": bench_rows}
     for name, fn in table.items():
         if which in ("all", name):
             fn()

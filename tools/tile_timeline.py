@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Developer tool (needs a SGLK_DEV_ABLATE build): per-workgroup timeline of the two grouped GEMMs of fused_experts at
-the bench shape -- prologue / main loop / epilogue durations and the gap between consecutive workgroups on a CU."""
+"""Developer tool (needs a SGLK_DEV_ABLATE build: `SGLK_DEV_ABLATE=1 python sgl-cpu-tests_amd/build.py`, then run this with
+SGLK_LIB_PATH=sgl-cpu-tests_amd/sgl_kernel/libsglk_dev.so): per-workgroup timeline of the two grouped GEMMs of fused_experts
+at the bench shape -- prologue / main loop / epilogue durations and the gap between consecutive workgroups on a CU.
+SGLK_FP8_ACT=1 in the environment looks at the a8 kernels instead."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
