@@ -282,6 +282,8 @@ def main():
                 32: "gstream::moe_gemm_fp8w_stream_kernel", 128: "moe_gemm_fp8w_kernel (128-row)"}.get(tile, f"tile {tile}")
         if p & _lib.PATH_FP8_ACT:
             kern = "ga8::moe_gemm_a8_kernel"
+        if p & _lib.PATH_SPLIT:
+            kern = "gsp::moe_gemm_fp8w_split_kernel (bf16 activations as two exact e4m3 terms, scaled fp8 MFMA)"
         return kern, tile
 
     # ---- oracle check of the LAST timed step's output (outside the timed region): >= 64 token rows through the plain-C

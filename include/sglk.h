@@ -144,7 +144,8 @@ enum {
     SGLK_PATH_PERSIST_G1 = 0x8000,    /* GEMM-1 launched persistent (one workgroup per CU, tile loop + tickets) */
     SGLK_PATH_PERSIST_G2 = 0x10000,   /* GEMM-2 launched persistent */
     SGLK_PATH_ROUTE_ALIGN = 0x20000,  /* sglk_moe_block: router + align ran as one launch */
-    SGLK_PATH_SHARED_FOLDED = 0x40000 /* sglk_moe_block: routed combine folded into the shared expert's last launch */
+    SGLK_PATH_SHARED_FOLDED = 0x40000,/* sglk_moe_block: routed combine folded into the shared expert's last launch */
+    SGLK_PATH_SPLIT = 0x80000         /* W8A16 with the activations as two exact e4m3 terms on the scaled fp8 MFMA */
 };
 
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);
@@ -194,6 +195,15 @@ int sglk_moe_block(const sglk_moe_block_args* args, void* stream);
  * k = 16h + {q | 32+q-8 | 8+q-16 | 40+q-24}), the order sglk_fused_experts' a8 kernels read.  No reference counterpart
  * (the reference's fp8 op keeps bf16 activations, /root/reference/bench_moe.py:113-130). */
 int sglk_quant_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale, int64_t scale_stride,
+                            int64_t rows, int32_t cols, void* stream);
+
+/* First stage of the W8A16 path on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip), exported so that the exactness of
+ * the split can be checked on its own: x [rows][cols] bf16 -> q [rows][2*cols] bytes + scale [rows][scale_stride] E8M0 bytes.
+ * Per 128-wide block: s = 2^(byte-127), the smallest power of two with amax / s <= 448 (byte >= 5); per element
+ * hi = e4m3(x / s), lo = e4m3((x - hi * s) / (s / 16)): x == hi * s + lo * s / 16 EXACTLY for every element within 2^13 of
+ * its block's amax.  q holds, per 64-wide k group, [hi 64 bytes | lo 64 bytes] in the packed-tile k order (see
+ * sglk_quant_fp8_block128).  No reference counterpart (internal stage of fused_experts_cpu, /root/reference/bench_moe.py:113-130). */
+int sglk_split_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale, int64_t scale_stride,
                             int64_t rows, int32_t cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

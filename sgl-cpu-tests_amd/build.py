@@ -21,13 +21,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-fno-gpu-rdc", "-I", os.path.join(HERE, "..", "include")]
 if os.environ.get("SGLK_EXTRA_FLAGS"):     # developer experiments, e.g. -DSGLK_DMA_SLOT_A=5
     FLAGS += os.environ["SGLK_EXTRA_FLAGS"].split()
-if os.environ.get("SGLK_BUILD_TAG"):        # developer A/B builds (with SGLK_EXTRA_FLAGS): libsglk_<tag>.so beside the product library
-    OUT = os.path.join(HERE, "sgl_kernel", "libsglk_%s.so" % os.environ["SGLK_BUILD_TAG"])
-    OBJ = os.path.join(HERE, "build", "obj_" + os.environ["SGLK_BUILD_TAG"])
-if os.environ.get("SGLK_DEV_ABLATE"):      # developer-only build (in-kernel time stamps, timing ablations): its own library,
-    FLAGS.append("-DSGLK_DEV_ABLATE")      # loaded with SGLK_LIB_PATH=.../libsglk_dev.so; the product library is untouched
-    OUT = os.path.join(HERE, "sgl_kernel", "libsglk_dev.so")
-    OBJ = os.path.join(HERE, "build", "obj_dev")
+_suffix = ""
+if os.environ.get("SGLK_DEV_ABLATE"):      # developer-only build (in-kernel time stamps): its own library, loaded with
+    FLAGS.append("-DSGLK_DEV_ABLATE")      # SGLK_LIB_PATH=.../libsglk_dev.so; the product library is untouched
+    _suffix += "_dev"
+if os.environ.get("SGLK_BUILD_TAG"):        # developer A/B builds (with SGLK_EXTRA_FLAGS): libsglk[_dev]_<tag>.so
+    _suffix += "_" + os.environ["SGLK_BUILD_TAG"]
+if _suffix:
+    OUT = os.path.join(HERE, "sgl_kernel", "libsglk%s.so" % _suffix)
+    OBJ = os.path.join(HERE, "build", "obj" + _suffix)
 
 
 def _newer(a, b):

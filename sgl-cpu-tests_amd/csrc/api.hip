@@ -45,6 +45,7 @@ void read_env() {
     k.max_wgs = env_int("SGLK_MAX_WGS", 0);
     k.attn_order = env_int("SGLK_ATTN_ORDER", -1);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
+    k.split = env_int("SGLK_SPLIT", -1);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);
     k.rescale_ablate = env_int("SGLK_RESCALE", 0);
     if (const char* dp = getenv("SGLK_DBG_PTR")) k.dbg_ptr = strtoull(dp, nullptr, 16);

@@ -11,6 +11,8 @@ using namespace sglk;
 
 namespace {
 
+constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
+
 struct StageTimer {
     int max_calls = 0, calls = 0;
     std::vector<hipEvent_t> ev;   // (SGLK_NUM_STAGES + 1) events per call
@@ -75,6 +77,11 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype, int fl
     w.tickets = take(16 * sizeof(int));
     w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
+    if (wtype == SGLK_W_FP8_E4M3 && !(flags & SGLK_MOE_FP8_ACT)) {   // two-term split of `hidden` (ic1's split rows take ic1's own place)
+        w.xq = take((size_t)M * 2 * K);
+        w.xs = take((size_t)M * align_up(K / 128, 4));
+        w.ic1s = take((size_t)S * align_up(N / 128, 4));
+    }
     if (wtype == SGLK_W_FP8_E4M3 && (flags & SGLK_MOE_FP8_ACT)) {   // a8 mode: e4m3 copies + one e8m0 scale per 128-wide block
         w.xq = take((size_t)M * K);
         w.xs = take((size_t)M * align_up(K / 128, 4));
@@ -274,7 +281,132 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
-    if (a8) {
+    // 256-row regime: the two-term e4m3 split on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip) instead of the
+    // bf16-MFMA kernel -- the same W8A16 contract (SGLK_SPLIT=0 / 1 overrides)
+    const bool split = tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
+                       (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault);
+    if (split) {
+        uint8_t* xq = ws + w.xq;
+        uint8_t* xs = ws + w.xs;
+        uint8_t* ic1q = (uint8_t*)ic1;                 // split rows [position][2N] bytes: exactly the bf16 ic1's footprint
+        uint8_t* ic1s = ws + w.ic1s;
+        const int xs_stride = (int)align_up(K / 128, 4), ic1s_stride = (int)align_up(N / 128, 4);
+        rc = launch_split_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, 2 * (int64_t)K, xs, xs_stride, M, K, s);
+        if (rc != SGLK_OK) return rc;
+        mark(1);   // the split pass counts towards the align stage
+        hipEvent_t ev_join = nullptr;
+        if (split_tails) {   // the short tail tiles run on the weight-streaming bf16-MFMA kernel (their own rows of ic1 / ic2)
+            const int tails_max = E < max_tiles ? E : max_tiles;
+            MoeGemmParams t1{};
+            t1.x = (const uint16_t*)a->hidden;
+            t1.x_stride = a->hidden_stride;
+            t1.x_bytes = (int64_t)M * a->hidden_stride * 2;
+            t1.sorted_slot = sorted_slot;
+            t1.topk = topk;
+            t1.w = (const uint8_t*)a->w1;
+            t1.w_expert_stride = (int64_t)2 * N * K;
+            t1.w_scale = a->w1_scale;
+            t1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+            t1.scale_cols = K / 128;
+            t1.block_n = a->block_n;
+            t1.C = K;
+            t1.n_half = N;
+            t1.tile_info = (const int4*)tile_info_b;
+            t1.num_tiles = num_tiles_b;
+            t1.n_tiles = N / 128;
+            t1.out = ic1;
+            t1.out_stride = N;
+            MoeGemmParams t2{};
+            t2.x = ic1;
+            t2.x_stride = N;
+            t2.x_bytes = (int64_t)M * topk * N * 2;
+            t2.sorted_slot = sorted_slot;
+            t2.topk = topk;
+            t2.w = (const uint8_t*)a->w2;
+            t2.w_expert_stride = (int64_t)K * N;
+            t2.w_scale = a->w2_scale;
+            t2.scale_rows = (int)ceil_div(K, a->block_n);
+            t2.scale_cols = N / 128;
+            t2.block_n = a->block_n;
+            t2.C = N;
+            t2.tile_info = (const int4*)tile_info_b;
+            t2.num_tiles = num_tiles_b;
+            t2.n_tiles = K / 128;
+            t2.out = ic2;
+            t2.out_stride = K;
+            t2.topk_weights = a->topk_weights;
+            hipStream_t ts = s;
+            if (side) {
+                hipEvent_t ev_fork = (hipEvent_t)a->aux_events[0];
+                ev_join = (hipEvent_t)a->aux_events[1];
+                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent((hipStream_t)a->aux_stream, ev_fork, 0) != hipSuccess)
+                    SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream fork failed");
+                ts = (hipStream_t)a->aux_stream;
+            }
+            rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, t1, tails_max, ts);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
+            if (rc != SGLK_OK) return rc;
+            if (side && hipEventRecord(ev_join, ts) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream record failed");
+        }
+        A8GemmParams q1{};
+        q1.x = xq;
+        q1.x_stride = 2 * (int64_t)K;
+        q1.x_bytes = (int64_t)M * 2 * K;
+        q1.xs = xs;
+        q1.xs_stride = xs_stride;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_expert_stride = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = (int)ceil_div(2 * N, a->block_n);
+        q1.scale_cols = K / 128;
+        q1.block_n = a->block_n;
+        q1.C = K;
+        q1.n_half = N;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.n_tiles = N / 128;
+        q1.out = ic1q;
+        q1.out_stride = 2 * (int64_t)N;
+        q1.out_s = ic1s;
+        q1.out_s_stride = ic1s_stride;
+#ifdef SGLK_DEV_ABLATE
+        if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
+#endif
+        rc = launch_moe_gemm_fp8w_split(MODE_GATE_UP, q1, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        A8GemmParams q2{};
+        q2.x = ic1q;
+        q2.x_stride = 2 * (int64_t)N;
+        q2.x_bytes = (int64_t)M * topk * 2 * N;
+        q2.xs = ic1s;
+        q2.xs_stride = ic1s_stride;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_expert_stride = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = (int)ceil_div(K, a->block_n);
+        q2.scale_cols = N / 128;
+        q2.block_n = a->block_n;
+        q2.C = N;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.n_tiles = K / 256;
+        q2.out = ic2;
+        q2.out_stride = K;
+        q2.topk_weights = a->topk_weights;
+#ifdef SGLK_DEV_ABLATE
+        if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
+#endif
+        rc = launch_moe_gemm_fp8w_split(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream join failed");
+        mark(3);
+    } else if (a8) {
         // quantise hidden (one pass), GEMM-1 + SiLU*mul + ic1 quantisation, GEMM-2 + routing weight (moe_gemm_a8.hip)
         uint8_t* xq = ws + w.xq;
         uint8_t* xs = ws + w.xs;
@@ -736,9 +868,9 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     }
     mark(4);
     if (a->path_taken) {
-        int path = (tile_m & SGLK_PATH_TILE_MASK) | (a8 ? SGLK_PATH_FP8_ACT : 0);
+        int path = (tile_m & SGLK_PATH_TILE_MASK) | (a8 ? SGLK_PATH_FP8_ACT : 0) | (split ? SGLK_PATH_SPLIT : 0);
         if (split_tails) path |= SGLK_PATH_TAILS_SPLIT | (side ? SGLK_PATH_TAILS_AUX : 0);
-        if (tuned && !a8 && tile_m == 256) {
+        if (tuned && !a8 && !split && tile_m == 256) {
             if (moe_gemm_fp8w_256i_is_persistent(K, (int64_t)max_tiles * (N / 128))) path |= SGLK_PATH_PERSIST_G1;
             if (moe_gemm_fp8w_256i_is_persistent(N, (int64_t)max_tiles * (K / 256))) path |= SGLK_PATH_PERSIST_G2;
         }
@@ -857,5 +989,14 @@ extern "C" int sglk_quant_fp8_block128(const void* x, int64_t x_stride, void* q,
     SGLK_REQUIRE(rows == 0 || (x && q && scale), SGLK_ERR_INVALID, "quant_fp8_block128: null pointer");
     SGLK_REQUIRE(x_stride >= cols && q_stride >= cols && scale_stride >= cols / 128, SGLK_ERR_INVALID, "quant_fp8_block128: stride");
     return launch_quant_fp8_block128((const uint16_t*)x, x_stride, (uint8_t*)q, q_stride, (uint8_t*)scale, scale_stride, rows, cols,
+                                     (hipStream_t)stream);
+}
+
+extern "C" int sglk_split_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale,
+                                       int64_t scale_stride, int64_t rows, int32_t cols, void* stream) {
+    SGLK_REQUIRE(rows >= 0 && cols > 0, SGLK_ERR_INVALID, "split_fp8_block128: bad sizes");
+    SGLK_REQUIRE(rows == 0 || (x && q && scale), SGLK_ERR_INVALID, "split_fp8_block128: null pointer");
+    SGLK_REQUIRE(x_stride >= cols && q_stride >= 2 * (int64_t)cols && scale_stride >= cols / 128, SGLK_ERR_INVALID, "split_fp8_block128: stride");
+    return launch_split_fp8_block128((const uint16_t*)x, x_stride, (uint8_t*)q, q_stride, (uint8_t*)scale, scale_stride, rows, cols,
                                      (hipStream_t)stream);
 }

@@ -24,6 +24,7 @@ struct Knobs {
                                  //               workgroup on small problems); 0 = one per CU
     int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
     bool no_block_fold = false;  // SGLK_NO_BLOCK_FOLD: sglk_moe_block runs router / align / combine / shared expert unfused (A/B)
+    int split = -1;              // SGLK_SPLIT: 0 = bf16-MFMA 256-row kernel, 1 = two-term e4m3 split on the scaled fp8 MFMA; unset = default
     int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)
     int rescale_ablate = 0;      // SGLK_RESCALE (SGLK_DEV_ABLATE builds only)
     unsigned long long dbg_ptr = 0;   // SGLK_DBG_PTR (SGLK_DEV_ABLATE builds only)

@@ -204,10 +204,9 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
 #pragma unroll
         for (int i = 0; i < kMaxKB / 4; ++i)
             if (i * 4 < kblocks) xs_reg[i] = sp[i];
-        if (MODE == MODE_DOWN) {
-            my_slot = slot;
-            my_tw = p.topk_weights[slot];
-        }
+        // DOWN: the routing weight (a load that DEPENDS on `slot`) is only needed by the epilogue and is fetched near the end
+        // of the main loop: here it would make the in-order wave wait for `slot` before any DMA stage could go out
+        if (MODE == MODE_DOWN) my_slot = slot;
     }
 
     // ---- LDS-DMA sources: descriptors in SGPRs + one 32-bit lane offset per piece; the stage offset is the scalar soffset.
@@ -232,7 +231,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
         xsrc[i] = off;
         wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * ctiles) * 1024u + lane * 16;
     }
+#ifdef SGLK_A8_ABLATE   // developer A/B builds only (-DSGLK_A8_ABLATE=bits; wrong results by design): 1 no rescale, 2 no DMA
+    constexpr int abl = SGLK_A8_ABLATE;   // after the prologue, 4 no fragment reads in the loop
+#else
+    constexpr int abl = 0;
+#endif
     auto issue_piece = [&](int kt, int buf, int i) {   // i = 0,1: X pieces; 2,3: W pieces of this wave
+        if ((abl & 2) && kt > 3) return;
         unsigned char* sx = smem + buf * kStage;
         if (i < 2)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_a8_t)(sx + (wave * 2 + i) * 1024), 16, xsrc[i], kt * 64, 0, 0);
@@ -282,10 +287,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
 #pragma unroll
                 for (int b = 0; b < 4; ++b) xs_tab[(i * 4 + b) * kBM + tid] = (unsigned char)(xs_reg[i] >> (8 * b));
             }
-        if (MODE == MODE_DOWN) {
-            slot_tab[tid] = my_slot;
-            tw_tab[tid] = my_tw;
-        }
+        if (MODE == MODE_DOWN) slot_tab[tid] = my_slot;
     }
     asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -308,15 +310,17 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
     for (int tt = 0; tt < 4; ++tt) xsv_next[tt] = xsv[tt];
 
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
-    i32x8 fa[2], fb[4];
+    i32x8 fa[2] = {}, fb[4] = {};
     float nsc[2] = {0.f, 0.f};
     auto ld_a = [&](i32x8& dst, int rt, int buf) {
+        if (abl & 4) return;
         const unsigned char* b = smem + (buf * kStage + woff0);
         const i32x4 lo = *reinterpret_cast<const i32x4*>(b + rt * kRt1);
         const i32x4 hi = *reinterpret_cast<const i32x4*>(b + rt * kRt1 + 256);
         dst = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
     auto ld_b = [&](i32x8& dst, int tt, int buf) {
+        if (abl & 4) return;
         const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + (buf * kStage + xoff0) + tt * 2048);
         const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + (buf * kStage + xoff1) + tt * 2048);
         dst = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -331,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
     };
     auto rescale = [&](int s2) {   // accumulator of slot s2 into units of the next K block's mantissa
         const int rt = s2 >> 2, tt = s2 & 3;
+        if (abl & 1) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][i]) : "s"(ratio[rt]));
     };
@@ -457,11 +462,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
             // t == T - 4
             stage(t, true, false, 8, false, true, true, true);
             stage(t + 1, false, true, 4, false, true, true, false);
+            if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];   // covered by the next stage's vmcnt(0)
             stage(t + 2, true, false, 0, false, true, true, false);
             stage(t + 3, false, false, -1, false, true, true, false);
         } else {   // kblocks == 2: stages 0..3, no stage 4
             stage(0, true, false, 8, false, false, false, true);
             stage(1, false, true, 4, false, false, true, false);
+            if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];
             stage(2, true, false, 0, false, true, true, false);
             stage(3, false, false, -1, false, true, true, false);
         }
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_a8_kernel(const A8GemmParams 
     }
 #undef SGLK_FENCE
     SGLK_STAMP(20);
+    if (MODE == MODE_DOWN && tid < kBM) tw_tab[tid] = my_tw;   // rows of tile rows 0..255 = waves 0..3, always active
 
     // ---- epilogue (ring dead).  32x32 accumulator: lane = token column (l & 31); register i = weight row
     //      (i & 3) + 8 * (i >> 2) + 4 * (l >> 5) of the row tile ----

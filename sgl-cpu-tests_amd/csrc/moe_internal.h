@@ -75,6 +75,11 @@ struct A8GemmParams {
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
 int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+// W8A16 with EXACT bf16 activations as two e4m3 terms (hi + lo) on the block-scaled fp8 matrix cores (moe_gemm_fp8w_split.hip):
+// x / ic1 rows are [hi 64 | lo 64] per 64-wide k group (x_stride / out_stride = 2 * C bytes), one E8M0 byte per 128 block
+int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
+                              int64_t rows, int cols, hipStream_t stream);
 // hidden bf16 [rows][cols] -> e4m3 (packed-tile k order) + one E8M0 byte per 128-wide block
 int launch_quant_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
                               int64_t rows, int cols, hipStream_t stream);

@@ -9,7 +9,7 @@ W_BF16, W_FP8_E4M3, W_INT8 = 0, 1, 2
 MOE_FP8_ACT = 1                      # sglk_fused_experts_args.flags
 PATH_TILE_MASK, PATH_FP8_ACT, PATH_TAILS_SPLIT, PATH_TAILS_AUX, PATH_PERSIST_G1, PATH_PERSIST_G2 = (
     0x3ff, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000)
-PATH_ROUTE_ALIGN, PATH_SHARED_FOLDED = 0x20000, 0x40000
+PATH_ROUTE_ALIGN, PATH_SHARED_FOLDED, PATH_SPLIT = 0x20000, 0x40000, 0x80000
 
 
 class FusedExpertsArgs(ctypes.Structure):
@@ -137,6 +137,8 @@ _SIGNATURES = {
     "sglk_moe_block_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 8),
     "sglk_moe_block": (ctypes.c_int, [ctypes.POINTER(MoeBlockArgs), ctypes.c_void_p]),
     "sglk_quant_fp8_block128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
+    "sglk_split_fp8_block128": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]),
     "sglk_moe_align_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 3),
     "sglk_moe_max_tiles": (ctypes.c_int32, [ctypes.c_int32] * 4),

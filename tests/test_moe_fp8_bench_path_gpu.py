@@ -24,8 +24,7 @@ def ops():
     return torch.ops.sgl_kernel
 
 
-@pytest.fixture(scope="module")
-def qwen3(ops):
+def make_qwen3(ops):
     """All 128 experts' fp8 weights (604 MB), generated on the GPU like bench.py:make_inputs; packed once."""
     g = torch.Generator(device="cuda").manual_seed(4321)
     w1 = (torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn)
@@ -35,6 +34,11 @@ def qwen3(ops):
     d = dict(w1=w1.cpu(), w2=w2.cpu(), w1s=w1s, w2s=w2s, w1p=ops.convert_weight_packed(w1), w2p=ops.convert_weight_packed(w2))
     del w1, w2
     return d
+
+
+@pytest.fixture(scope="module")
+def qwen3(ops):
+    return make_qwen3(ops)
 
 
 def routed_inputs(M, seed):
