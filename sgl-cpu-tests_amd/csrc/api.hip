@@ -43,6 +43,8 @@ void read_env() {
     k.wide_n = env_set("SGLK_WIDE_N");
     k.persist = env_int("SGLK_PERSIST", -1);
     k.max_wgs = env_int("SGLK_MAX_WGS", 0);
+    k.dec_splits = env_int("SGLK_DEC_SPLITS", 0);
+    k.attn_nw = env_int("SGLK_ATTN_NW", 0);
     k.attn_order = env_int("SGLK_ATTN_ORDER", -1);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
     k.split = env_int("SGLK_SPLIT", -1);

@@ -328,12 +328,13 @@ static int attn_order(int dflt) {   // A/B override: bit 0 = flip second wave, b
 // FORM (compile time, so that the extend form pays nothing for the others): 0 = extend_attention_cpu (paged prefix +
 // causal extend part, exact head dims); 1 = flash_attn_varlen_func with head dims equal to D / DV and 16-byte aligned
 // rows; 2 = flash_attn_varlen_func with zero-padded head dims and / or rows that are only 4-byte aligned.
-template <int D, int DV, int QT, int FORM>
-__global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendParams p) {
+// NW = waves per workgroup: 8 (two per SIMD: one wave's softmax beside the other's MFMAs), or 4 (A/B knob) -- then two
+// workgroups share a CU the same way, each streaming its own K/V tiles, with half the queries per workgroup.
+template <int D, int DV, int QT, int FORM, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const ExtendParams p) {
     constexpr bool VARLEN = FORM != 0, RAGGED = FORM == 2;
-    // queries per workgroup: 8 waves (two per SIMD: one wave's softmax beside the other's MFMAs) x QT tiles x 16
-    // (QT = 2 where the register budget of 256 per lane allows it)
-    constexpr int QB = 8 * QT * 16;
+    // queries per workgroup: NW waves x QT tiles x 16 (QT = 2 where the register budget of 256 per lane allows it)
+    constexpr int QB = NW * QT * 16;
     constexpr int WQ = QT * 16;   // queries per wave
     constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KB + VB)];   // two {K, V} tile buffers
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(512, 2) void extend_attention_kernel(const ExtendPa
     const int ntiles = (kv_end + kKeys - 1) / kKeys;
 
     // software pipeline: tile i+1 travels HBM -> registers while tile i is multiplied out of LDS
-    TileRegs<D, 512> kreg;
-    TileRegs<DV, 512> vreg;
+    TileRegs<D, NW * 64> kreg;
+    TileRegs<DV, NW * 64> vreg;
     // a wave's 32 queries see keys < wave_kv_end: later tiles of the workgroup's stream are fully masked for it
     const int wave_q_last = (q0 + wave * WQ + WQ < ext_len) ? q0 + wave * WQ + WQ : ext_len;
     const int wave_kv_end = causal ? (prefix + wave_q_last < n_keys ? prefix + wave_q_last : n_keys) : n_keys;
@@ -490,7 +491,7 @@ struct DecodeParams {
     int rtt_is64;
     const int64_t* b_req_idx;
     const int64_t* b_seq_len;
-    int HQ, HKV, splits, v_alias;
+    int HQ, HKV, splits, logit_splits, v_alias;   // splits used / depth of the caller's scratch
     float sm_scale, logit_cap;
 };
 
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
         core.m[0] = mt;
     }
     if (!col_valid) return;
-    float* dst = p.logits + (((int64_t)b * p.HQ + h) * p.splits + split) * (DV + 1);
+    float* dst = p.logits + (((int64_t)b * p.HQ + h) * p.logit_splits + split) * (DV + 1);
     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
     const int g4 = (lane >> 4) * 4;
 #pragma unroll
@@ -702,9 +703,9 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
 }
 
 __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restrict__ logits, unsigned short* __restrict__ o,
-                                                           int64_t o_s0, int64_t o_s1, int HQ, int splits, int DV) {
+                                                           int64_t o_s0, int64_t o_s1, int HQ, int splits, int logit_splits, int DV) {
     const int b = blockIdx.x, h = blockIdx.y;
-    const float* src = logits + ((int64_t)b * HQ + h) * splits * (DV + 1);
+    const float* src = logits + ((int64_t)b * HQ + h) * logit_splits * (DV + 1);
     float mx = -INFINITY;
     for (int s = 0; s < splits; ++s) mx = fmaxf(mx, src[s * (DV + 1) + DV]);
     float wsum = 0.f;
@@ -753,17 +754,23 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
     const int64_t strides[] = {p.q_s0, p.q_s1, p.ke_s0, p.ke_s1, p.ve_s0, p.ve_s1, p.kb_s0, p.kb_s1, p.vb_s0, p.vb_s1};
     for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "extend_attention: q/k/v strides must be multiples of 8 elements");
     SGLK_REQUIRE(p.o_s0 % 4 == 0 && p.o_s1 % 4 == 0, SGLK_ERR_SHAPE, "extend_attention: o strides must be multiples of 4 elements");
-    const dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
     p.B = a->B; p.n_cu = attn_cus(); p.order = attn_order(2);
+    // SGLK_ATTN_NW=4: 4-wave workgroups (twice as many, half the queries each).  Measured at B = 1, 4096 x 32 heads: 0.275 vs
+    // 0.231 ms -- the better balance of the causal launch does not pay for two workgroups per CU each staging their own K/V
+    // tiles; kept as an A/B knob, never chosen by default.
 #define EXT_CASE(DD, DDV)                                                                              \
     if (a->D == DD && a->DV == DDV) {                                                                  \
         constexpr int QT = DD > 128 ? 1 : 2;                                                           \
-        p.nqblk = (int)ceil_div(a->max_len_extend, 8 * QT * 16);                                       \
+        const int64_t wgs8 = ceil_div(a->max_len_extend, 8 * QT * 16) * a->B * a->HQ;                  \
+        const bool nw4 = knobs().attn_nw == 4; (void)wgs8;                                             \
+        const int nw = nw4 ? 4 : 8;                                                                    \
+        p.nqblk = (int)ceil_div(a->max_len_extend, nw * QT * 16);                                      \
         const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;                                           \
         SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "extend_attention: too many workgroups");      \
         const dim3 grid((unsigned)wgs);                                                                \
-        hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0>), grid, block, 0, s, p);              \
+        if (nw4) hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0, 4>), grid, dim3(256), 0, s, p); \
+        else hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0, 8>), grid, dim3(512), 0, s, p);  \
         SGLK_CHECK_LAUNCH("extend_attention");                                                         \
         return SGLK_OK;                                                                                \
     }
@@ -854,12 +861,28 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     p.q_s0 = a->q_stride[0]; p.q_s1 = a->q_stride[1]; p.kb_s0 = a->k_buffer_stride[0]; p.kb_s1 = a->k_buffer_stride[1];
     p.vb_s0 = a->v_buffer_stride[0]; p.vb_s1 = a->v_buffer_stride[1]; p.logits = a->attn_logits;
     p.req_to_token = a->req_to_token; p.rtt_stride = a->req_to_token_stride; p.rtt_is64 = a->req_to_token_is64;
-    p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.HQ = a->HQ; p.HKV = a->HKV; p.splits = a->splits;
+    p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.HQ = a->HQ; p.HKV = a->HKV;
+    // Splits actually used (<= the caller's scratch depth; the merge reads only these): every (request, kv head, split) is one
+    // workgroup and a wide-head (D >= 256) workgroup owns a CU, so more workgroups than CUs run in ROUNDS that each pay the
+    // prologue (page lookups, first tile) again.  Use the most splits that still fit one round (SGLK_DEC_SPLITS=n forces n, -1 =
+    // all).  Measured (MLA, D = 576): B = 40 x 1064 keys 45.7 -> 32.9 us, B = 128 x 4096 keys 177 -> 134 us (3.4 -> 4.5 TB/s).
+    int eff = a->splits;
+    {
+        const int64_t per_split = (int64_t)a->B * a->HKV;
+        const int cus = attn_cus();
+        if (knobs().dec_splits > 0) eff = knobs().dec_splits < a->splits ? knobs().dec_splits : a->splits;
+        else if (knobs().dec_splits == 0 && a->D >= 256 && per_split * eff > cus) {   // narrow heads: several workgroups share a CU
+            eff = (int)(cus / per_split);
+            if (eff < 1) eff = 1;
+        }
+    }
+    p.splits = eff;
+    p.logit_splits = a->splits;
     p.sm_scale = a->sm_scale; p.logit_cap = a->logit_cap;
     // V aliases K when it is the same storage with the same strides (MLA: v = k[..., :DV])
     const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
                        a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
-    const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)a->splits);
+    const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)eff);
     const int group = a->HQ / a->HKV;
 #define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
     {                                                                                                              \
@@ -882,7 +905,7 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
         }                                                                                                          \
         SGLK_CHECK_LAUNCH("decode_attention");                                                                     \
         hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)a->B, (unsigned)a->HQ), dim3(256), 0, s, a->attn_logits,    \
-                           (unsigned short*)a->o, a->o_stride[0], a->o_stride[1], a->HQ, a->splits, a->DV);        \
+                           (unsigned short*)a->o, a->o_stride[0], a->o_stride[1], a->HQ, eff, a->splits, a->DV);   \
         SGLK_CHECK_LAUNCH("decode_attention(merge)");                                                              \
         return SGLK_OK;                                                                                            \
     }

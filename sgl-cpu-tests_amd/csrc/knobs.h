@@ -22,6 +22,8 @@ struct Knobs {
     int persist = -1;            // SGLK_PERSIST: 0 = one workgroup per tile, 1 = persistent; unset = by reduction length
     int max_wgs = 0;             // SGLK_MAX_WGS: cap on the persistent launches' workgroups (tests: forces many tiles per
                                  //               workgroup on small problems); 0 = one per CU
+    int dec_splits = 0;          // SGLK_DEC_SPLITS: KV splits decode_attention uses (0 = one round of workgroups, -1 = all the scratch has)
+    int attn_nw = 0;             // SGLK_ATTN_NW: waves per extend-attention workgroup (4 / 8); 0 = by launch size
     int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
     bool no_block_fold = false;  // SGLK_NO_BLOCK_FOLD: sglk_moe_block runs router / align / combine / shared expert unfused (A/B)
     int split = -1;              // SGLK_SPLIT: 0 = bf16-MFMA 256-row kernel, 1 = two-term e4m3 split on the scaled fp8 MFMA; unset = default
