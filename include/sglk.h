@@ -266,6 +266,27 @@ typedef struct {
 size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
 int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Direct all-reduce over xGMI peer memory     replaces the ROLE of sgl_kernel.common_ops.shm_allreduce
+ *     (/root/reference/test_allreduce.py:86-105: a shared-memory all-reduce between the CPU ranks of one host; bench message
+ *      1024 x 5120 bf16 = 10 MiB, run_allreduce_cpu.sh:8-12).  One process per GPU; every rank allocates a staging region of
+ *      4 * capacity bytes and 256 bytes of flag words with sglk_comm_alloc, exports both with sglk_ipc_export, exchanges the
+ *      64-byte handles out of band (torch.distributed object all-gather in sgl_kernel/collectives.py) and maps its peers' with
+ *      sglk_ipc_open.  sglk_allreduce_sum_bf16 then sums `n_elems` bf16 values of all ranks (fp32, ascending rank order, one
+ *      rounding: identical bits on every rank) from `in` to `out` (may alias): one-shot for small messages, two-shot
+ *      (reduce-scatter + all-gather of slices) for large ones -- direct reads use all 7 links of a GPU at once, a ring is bound
+ *      by one.  `epoch` must increase by one per call (the same value on every rank); *status_dev becomes non-zero when a
+ *      peer did not arrive within ~2 s (the kernels give up instead of hanging).  algo: 0 by size, 1 one-shot, 2 two-shot.
+ * --------------------------------------------------------------------------------------------------------- */
+int sglk_comm_alloc(size_t bytes, int32_t finegrained, void** dev_ptr /* host out */);
+void sglk_comm_free(void* dev_ptr);
+int sglk_ipc_export(const void* dev_ptr, void* handle64 /* host, 64 bytes out */);
+int sglk_ipc_open(const void* handle64 /* host */, void** dev_ptr /* host out */);
+int sglk_ipc_close(void* dev_ptr);
+int sglk_allreduce_sum_bf16(void* const* peer_data /* host [world] */, void* const* peer_flags /* host [world] */, int32_t rank,
+                            int32_t world, int64_t capacity_bytes, const void* in, void* out, int64_t n_elems, uint32_t epoch,
+                            int32_t algo, int32_t* status_dev, void* stream);
+
 /* Expert-parallel dispatch glue (sgl_kernel/expert_parallel.py; no reference counterpart -- the reference pins only the
  * local contract EP needs, topk_ids == -1 for non-resident experts: /root/reference/test_moe_offloading_cpu.py:12-15,62-68).
  * Rank d owns experts [d*E/G, (d+1)*E/G).

@@ -154,6 +154,14 @@ _SIGNATURES = {
     "sglk_per_token_quant_int8_floor": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_float,
                                                         ctypes.c_void_p]),
+    "sglk_comm_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "sglk_comm_free": (None, [ctypes.c_void_p]),
+    "sglk_ipc_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p]),
+    "sglk_ipc_open": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "sglk_ipc_close": (ctypes.c_int, [ctypes.c_void_p]),
+    "sglk_allreduce_sum_bf16": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                               ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "sglk_ep_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sglk_ep_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

@@ -2,8 +2,8 @@
 `initialize(world_size, rank)`, `shm_allreduce(tensor, group, op)` (in place) and `shm_allgather(tensor, group, dim)`.
 
 The reference moves CPU tensors through a shared-memory segment between the ranks of one host.  Here every rank owns one
-MI355X and the tensors live in HBM, so the same calls map to RCCL over xGMI through torch.distributed (backend "nccl"):
-the 10 MiB bf16 message of the reference bench (1024 x 5120) is one all-reduce across the 7 point-to-point links.  A
+MI355X and the tensors live in HBM.  bf16 sums go through XgmiAllReduce (below: direct peer reads over all 7 xGMI links,
+one-shot / two-shot) once one is registered for the group; everything else maps to torch.distributed (backend "nccl" = RCCL).  A
 "gloo" group works too - CPU tensors directly, GPU tensors staged through the host - which is what the CPU tests and
 single-GPU rehearsals use.  No sglang process-group wrapper is needed: `group` is a torch.distributed group (or None for
 the default one)."""
@@ -11,6 +11,87 @@ import torch
 import torch.distributed as dist
 
 _state = {"world_size": None, "rank": None}
+_xgmi = {}      # group -> XgmiAllReduce registered for it (shm_allreduce uses it for bf16 SUM on GPU tensors)
+
+
+class XgmiAllReduce:
+    """Direct all-reduce between the GPUs of one node over xGMI peer memory (sglk_allreduce_sum_bf16, include/sglk.h): every
+    rank maps its peers' staging regions through HIP IPC; one-shot for small messages, two-shot (reduce-scatter + all-gather of
+    slices) for large ones, fp32 sums in ascending rank order -- bit-identical on every rank.  The 64-byte IPC handles travel
+    through the torch.distributed group once, at construction; no collective of the group is used afterwards."""
+
+    def __init__(self, group=None, max_bytes=16 << 20, register=True):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        L = _lib.lib()
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > 8:
+            raise RuntimeError("XgmiAllReduce: at most 8 ranks (one node)")
+        self.cap = (int(max_bytes) + 255) // 256 * 256
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        data, flags = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(L.sglk_comm_alloc(4 * self.cap, 0, ctypes.byref(data)), "comm_alloc(data)")
+        _lib.check(L.sglk_comm_alloc(256, 1, ctypes.byref(flags)), "comm_alloc(flags)")
+        self._own = (data.value, flags.value)
+        hd, hf = ctypes.create_string_buffer(64), ctypes.create_string_buffer(64)
+        _lib.check(L.sglk_ipc_export(data, hd), "ipc_export(data)")
+        _lib.check(L.sglk_ipc_export(flags, hf), "ipc_export(flags)")
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, (bytes(hd.raw), bytes(hf.raw)), group=group)
+        self._opened = []
+        pd, pf = (ctypes.c_void_p * self.world)(), (ctypes.c_void_p * self.world)()
+        for r, (d, f) in enumerate(everyone):
+            if r == self.rank:
+                pd[r], pf[r] = data.value, flags.value
+                continue
+            od, of = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(L.sglk_ipc_open(d, ctypes.byref(od)), f"ipc_open(data of rank {r})")
+            _lib.check(L.sglk_ipc_open(f, ctypes.byref(of)), f"ipc_open(flags of rank {r})")
+            pd[r], pf[r] = od.value, of.value
+            self._opened += [od.value, of.value]
+        self._pd, self._pf = pd, pf
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.epoch = 0
+        dist.barrier(group=group)          # everybody has mapped everybody before the first call
+        if register:
+            _xgmi[group] = self
+
+    def supports(self, t):
+        return t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0 and \
+            t.numel() * 2 <= self.cap and t.data_ptr() % 16 == 0
+
+    def all_reduce(self, t, algo=0):
+        """In-place sum over the ranks (bf16).  algo: 0 by size, 1 one-shot, 2 two-shot."""
+        if not self.supports(t):
+            raise RuntimeError("XgmiAllReduce: contiguous 16-byte aligned bf16 CUDA tensors of a multiple of 8 elements, "
+                               f"at most {self.cap} bytes")
+        self.epoch += 1
+        ct = self._ct
+        self._lib.check(self._lib.lib().sglk_allreduce_sum_bf16(
+            self._pd, self._pf, self.rank, self.world, self.cap, ct.c_void_p(t.data_ptr()), ct.c_void_p(t.data_ptr()), t.numel(),
+            self.epoch & 0xFFFFFFFF, algo, ct.c_void_p(self.status.data_ptr()),
+            ct.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), "allreduce_sum_bf16")
+        return t
+
+    def check(self):
+        """Synchronises; raises if a peer failed to arrive in some call since the last check."""
+        if int(self.status.item()) != 0:
+            self.status.zero_()
+            raise RuntimeError("XgmiAllReduce: a peer did not arrive within the spin limit")
+
+    def close(self):
+        L = self._lib.lib()
+        torch.cuda.synchronize()
+        for p in self._opened:
+            L.sglk_ipc_close(p)
+        self._opened = []
+        if self._own:
+            L.sglk_comm_free(self._own[0])
+            L.sglk_comm_free(self._own[1])
+            self._own = None
+        _xgmi.pop(self.group, None)
 
 
 def initialize(world_size, rank):
@@ -32,7 +113,10 @@ def shm_allreduce(tensor, group=None, op=dist.ReduceOp.SUM):
     """In-place all-reduce (/root/reference/test_allreduce.py:103-105).  Returns None like the reference."""
     if not tensor.is_contiguous():
         raise RuntimeError("shm_allreduce: tensor must be contiguous")
-    if _host_staged(tensor, group):
+    comm = _xgmi.get(group)
+    if comm is not None and op == dist.ReduceOp.SUM and comm.supports(tensor):
+        comm.all_reduce(tensor)            # direct xGMI peer reads (XgmiAllReduce), not a ring
+    elif _host_staged(tensor, group):
         h = tensor.cpu()
         dist.all_reduce(h, op=op, group=group)
         tensor.copy_(h)
