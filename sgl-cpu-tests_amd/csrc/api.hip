@@ -46,6 +46,8 @@ void read_env() {
     k.dec_splits = env_int("SGLK_DEC_SPLITS", 0);
     k.attn_nw = env_int("SGLK_ATTN_NW", 0);
     k.attn_order = env_int("SGLK_ATTN_ORDER", -1);
+    k.attn_pair = env_int("SGLK_ATTN_PAIR", -1);
+    k.attn_pp = env_int("SGLK_ATTN_PP", -1);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
     k.split = env_int("SGLK_SPLIT", -1);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);
@@ -107,7 +109,13 @@ extern "C" int sglk_aux_create(void** stream, void** event0, void** event1) {
     SGLK_REQUIRE(stream && event0 && event1, SGLK_ERR_INVALID, "aux_create: null pointer");
     hipStream_t st = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+    // SGLK_AUX_PRIO=low|high: queue priority of the side stream (A/B knob; the tail tiles are filler work)
+    int lo = 0, hi = 0;
+    const char* pr = getenv("SGLK_AUX_PRIO");
+    const bool want = pr && (pr[0] == 'l' || pr[0] == 'h') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+    const hipError_t se = want ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr[0] == 'l' ? lo : hi)
+                               : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (se != hipSuccess ||
         hipEventCreateWithFlags(&e0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess) {
         if (e0) hipEventDestroy(e0);

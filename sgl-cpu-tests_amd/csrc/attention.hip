@@ -160,7 +160,9 @@ struct Core {
     // DV here is the width of the V slice this wave accumulates; dv0 = its first column inside the V image, whose rows
     // are VROW elements wide (0 = DV, i.e. the wave owns the whole width)
     // NKT = 16-key tiles this wave takes from the image (4 = all 64 keys; 2 = the 32 keys from row k0, decode kernel)
-    template <bool V_ALIAS, int VROW = 0, int NKT = 4>
+    // PIPE > 0 (extend kernel): the operand reads of both products are issued PIPE fragments ahead of the MFMAs that consume
+    // them (scheduling fences; left alone the scheduler keeps one or two reads in flight and each MFMA pair waits an LDS round trip)
+    template <bool V_ALIAS, int VROW = 0, int NKT = 4, int PIPE = 0>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
                        float scale_log2e, float logit_cap, int lane, int dv0 = 0, int k0 = 0) {
         int lim_min = limit[0];
@@ -189,6 +191,17 @@ struct Core {
                 for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
+        }
+        if constexpr (PIPE > 0) {
+            constexpr int NF = KS * NKT;
+            __builtin_amdgcn_sched_group_barrier(0x100, PIPE, 0);
+#pragma unroll
+            for (int i = 0; i < NF - PIPE; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < PIPE; ++i) __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
         }
         // ---- online softmax per column (lane) ----
         bf16x8 pf[QT][NKT / 2];
@@ -283,6 +296,17 @@ struct Core {
                     o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ss], o[qt][t], 0, 0, 0);
             }
         }
+        if constexpr (PIPE > 0) {
+            constexpr int NF = VT * (NKT / 2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PIPE, 1);
+#pragma unroll
+            for (int i = 0; i < NF - PIPE; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, QT, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            }
+#pragma unroll
+            for (int i = 0; i < PIPE; ++i) __builtin_amdgcn_sched_group_barrier(0x008, QT, 1);
+        }
     }
 
     // total of the per-lane partial sums of a column (the 4 lane groups hold disjoint keys)
@@ -317,7 +341,7 @@ struct ExtendParams {
     const int* cu_k;
     int d_real, dv_real;     // head dims of the tensors; the kernel's D / DV are these rounded up (zero-padded images)
     int v_aligned;           // V rows / chunks are 16-byte aligned
-    int B, nqblk, n_cu, order;   // launch geometry (see the kernel's workgroup-id decomposition)
+    int B, nqblk, n_cu, order, pair;   // launch geometry (see the kernel's workgroup-id decomposition)
 };
 
 static int attn_cus() { return device_cu_count(); }
@@ -325,11 +349,21 @@ static int attn_order(int dflt) {   // A/B override: bit 0 = flip second wave, b
     return knobs().attn_order >= 0 ? knobs().attn_order : dflt;
 }
 
+// heavy + light query blocks in one workgroup (see the kernel): SGLK_ATTN_PAIR = 0 / 1 overrides
+static int pair_blocks(int nqblk, int64_t wgs_unpaired, int n_cu, int causal) {
+    if (nqblk < 2 || !causal) return 0;
+    if (knobs().attn_pair >= 0) return knobs().attn_pair;
+    return wgs_unpaired <= 2 * (int64_t)n_cu ? 1 : 0;
+}
+
 // FORM (compile time, so that the extend form pays nothing for the others): 0 = extend_attention_cpu (paged prefix +
 // causal extend part, exact head dims); 1 = flash_attn_varlen_func with head dims equal to D / DV and 16-byte aligned
 // rows; 2 = flash_attn_varlen_func with zero-padded head dims and / or rows that are only 4-byte aligned.
 // NW = waves per workgroup: 8 (two per SIMD: one wave's softmax beside the other's MFMAs), or 4 (A/B knob) -- then two
 // workgroups share a CU the same way, each streaming its own K/V tiles, with half the queries per workgroup.
+#ifndef SGLK_EXT_PIPE
+#define SGLK_EXT_PIPE 0
+#endif
 template <int D, int DV, int QT, int FORM, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const ExtendParams p) {
     constexpr bool VARLEN = FORM != 0, RAGGED = FORM == 2;
@@ -352,9 +386,13 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const Exte
         if ((p.order & 1) && lin >= p.n_cu && lin < hi) lin = p.n_cu + hi - 1 - lin;
     }
     const int nqblk = p.nqblk;
-    int b, h, qblk;
-    if (p.order & 2) { h = lin % p.HQ; b = (lin / p.HQ) % p.B; qblk = lin / (p.HQ * p.B); }
-    else { qblk = lin % nqblk; b = (lin / nqblk) % p.B; h = lin / (nqblk * p.B); }
+    // p.pair: a workgroup takes TWO query blocks, the i-th heaviest and the i-th lightest of its (sequence, head), one after the
+    // other -- every workgroup of a causal launch then has the same work.  Chosen when the un-paired launch would be resident all
+    // at once (<= 2 workgroups per CU), where nothing is dispatched later to even the CUs out.
+    const int nitem = p.pair ? (nqblk + 1) / 2 : nqblk;
+    int b, h, qblk0;
+    if (p.order & 2) { h = lin % p.HQ; b = (lin / p.HQ) % p.B; qblk0 = lin / (p.HQ * p.B); }
+    else { qblk0 = lin % nitem; b = (lin / nitem) % p.B; h = lin / (nitem * p.B); }
     int ext_len, prefix, ext_start, k_start = 0, n_keys;
     if (VARLEN) {
         ext_start = p.cu_q[b];
@@ -370,15 +408,18 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const Exte
         n_keys = prefix + ext_len;
     }
     const bool causal = !VARLEN || p.causal;
-    // heaviest query blocks (most keys under the causal mask) first
-    const int q0 = (nqblk - 1 - qblk) * QB;
-    if (q0 >= ext_len) return;
     const int64_t req = VARLEN ? 0 : p.b_req_idx[b];
     const int kvh = h / (p.HQ / p.HKV);
     const int kvh_buf = p.HBUF == p.HKV ? kvh : 0;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d_real = RAGGED ? p.d_real : D, dv_real = RAGGED ? p.dv_real : DV;
+    for (int part = 0; part < (p.pair ? 2 : 1); ++part) {
+    const int qblk = part == 0 ? qblk0 : nqblk - 1 - qblk0;
+    if (part == 1 && qblk == qblk0) break;
+    // heaviest query blocks (most keys under the causal mask) first
+    const int q0 = (nqblk - 1 - qblk) * QB;
+    if (q0 >= ext_len) continue;
     Core<D, DV, QT> core;
     core.init();
     int limit[QT];
@@ -426,7 +467,8 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const Exte
             kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1), d_real, true);
             vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1), dv_real, v_al);
         }
-        if (t * kKeys < wave_kv_end) core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
+        if (t * kKeys < wave_kv_end)
+            core.template tile<false, 0, 4, SGLK_EXT_PIPE>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
         if (more) {
             kreg.store(nxt);      // `nxt` was last read in iteration t-1, which every wave left before this barrier's
             vreg.store(nxt + KB); // predecessor; the barrier below publishes it for iteration t+1
@@ -455,6 +497,448 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const Exte
                 if (c + 2 <= dv_real) *reinterpret_cast<unsigned*>(orow + c) = w.x;
                 if (c + 4 <= dv_real) *reinterpret_cast<unsigned*>(orow + c + 2) = w.y;
             }
+        }
+    }
+    }   // part
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// extend attention, two-phase form (D = DV = 128)
+// ---------------------------------------------------------------------------------------------------------------------
+// The kernel above keeps all eight waves of a workgroup in the same phase of a tile (one barrier per tile): the two waves of a
+// SIMD issue their Q.K MFMAs together, then both run the softmax on the VALU, then both issue the P.V MFMAs -- counters of the
+// Qwen3 prefill shape: matrix pipe busy 33 % of the cycles, VALU about 45 %, one after the other.  Per tile and wave the softmax
+// (32 exp2 at quarter rate plus ~200 other VALU instructions) costs as many cycles as the 64 MFMAs.
+// Here the waves form two groups that run HALF A TILE APART: a tile is a VALU slot V_t (softmax of S_t -> P_t) and a matrix
+// slot M_t (O += V_t^T P_t, then S_{t+1} = K_{t+1} Q^T), with a workgroup barrier after every slot; group A (waves 0-3) runs
+// V_t in slot 2t+1 and M_t in slot 2t+2, group B (waves 4-7, the SECOND wave of each SIMD) one slot later.  In every slot each
+// SIMD has one wave on the matrix pipe and one on the VALU.
+//   LDS: rings of three K and three V tiles (96 KiB).  M_t reads V_t and K_{t+1} in slots 2t+2 (A) and 2t+3 (B); tile halves
+//   K_{t+2} / V_{t+1} are written by each group during ITS V_t slot (2t+1 / 2t+2) into the buffers last read by M_{t-2}
+//   (slots 2t-2 / 2t-1), and are complete one barrier before M_{t+1} reads them (2t+4).  Their global loads are issued one
+//   slot earlier, so a load has a whole matrix slot to land.
+typedef const __attribute__((address_space(1))) void* dma_gptr_t;
+typedef __attribute__((address_space(3))) void* dma_lptr_t;
+
+// A group's half of a 64-row tile by LDS-DMA: 256 threads x 2 instructions of 16 bytes per lane, no registers, no ds_write.
+// The image is linear per wave (1 KiB per instruction), so the XOR swizzle is applied to the SOURCE chunk a lane fetches.
+// Rows past `nkeys` repeat the last real row (finite data: their probabilities are exactly 0).
+// V image of the two-phase kernel (16 chunks per row): chunk c of row r sits in slot c ^ vswz(r).  A ds_read_b64_tr_b16 of 32
+// lanes takes a 32-byte column pair from 8 consecutive rows; with the K image's 3-bit mask those fall into one 128-byte window
+// (half the banks, two passes), with the row number in bits 3:1 they cover all 64 banks.
+SGLK_DEV int vswz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+template <int WIDTH, int FORM, bool VIMG = false>
+struct HalfDma {
+    static constexpr int CH = WIDTH / 8;
+    const unsigned short* g[2];
+    SGLK_DEV void prep(const KvSource& src, int p0, int nkeys, int grp, int t256) {
+        constexpr int MASK = Swz<CH>::mask;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = grp * 512 + i * 256 + t256;
+            const int row = c / CH, slot = c - row * CH;
+            const int rr = row < nkeys ? row : nkeys - 1;
+            const int pos = p0 + rr;
+            const unsigned short* base;
+            if (FORM == 0) {
+                const int pi = pos < src.n_paged ? pos : 0;
+                int64_t tok = 0;
+                if (src.n_paged > 0)
+                    tok = src.page_is64 ? reinterpret_cast<const int64_t*>(src.page)[pi] : (int64_t)reinterpret_cast<const int*>(src.page)[pi];
+                const unsigned short* a = src.buf + tok * src.buf_stride_tok;
+                const unsigned short* b = src.ext + (int64_t)(pos - src.n_paged) * src.ext_stride_tok;
+                base = pos < src.n_paged ? a : b;
+            } else {
+                base = src.ext + (int64_t)pos * src.ext_stride_tok;
+            }
+            g[i] = base + ((slot ^ (VIMG ? vswz(row) : (row & MASK))) << 3);
+        }
+    }
+    SGLK_DEV void issue(unsigned char* lds, int grp, int wv) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)g[i], (dma_lptr_t)(lds + (grp * 512 + i * 256 + wv * 64) * 16), 16, 0, 0);
+    }
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max over the lanes l ^ 16 / l ^ 32 by row swaps (gfx950 v_permlane16_swap / v_permlane32_swap): with both operands the same
+// register the two results hold the two rows of every pair in all lanes of the pair
+SGLK_DEV float xor16_max(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+SGLK_DEV float xor32_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+struct CorePP {
+    static constexpr int D = 128, DV = 128, QT = 2, KS = 4, VT = 8, NKT = 4;
+#ifndef SGLK_PP_AHEAD
+#define SGLK_PP_AHEAD 4
+#endif
+    static constexpr int kAhead = SGLK_PP_AHEAD;   // operand fragments (16 bytes per lane) in flight ahead of the MFMAs
+    bf16x8 qf[QT][KS];
+    f32x4 o[QT][VT];
+    f32x4 s[QT][NKT];
+    bf16x8 pf[QT][NKT / 2];
+    float m[QT], l[QT];
+
+    SGLK_DEV void init() {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            m[qt] = -INFINITY;
+            l[qt] = 0.f;
+#pragma unroll
+            for (int t = 0; t < VT; ++t) o[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    SGLK_DEV void load_q(int qt, const unsigned short* qrow, int lane) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (qrow) v = *reinterpret_cast<const uint4*>(qrow + ks * 32 + g * 8);
+            qf[qt][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // S^T = K . Q^T of one 64-key tile.  Only ONE wave of a SIMD is in its matrix slot, so nothing else hides the LDS latency of
+    // the operand reads: they are issued eight fragments ahead of the MFMAs that consume them (scheduling fences pin the order;
+    // left alone the scheduler keeps one read in flight and every pair of MFMAs waits a full LDS round trip).
+    SGLK_DEV void qk(const unsigned char* klds, int lane) {
+        constexpr int KMASK = Swz<D / 8>::mask;
+        const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) s[qt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[KS * NKT];
+#pragma unroll
+        for (int i = 0; i < KS * NKT; ++i) {
+            const int ks = i / NKT, kt = i % NKT;
+            const int row = kt * 16 + r;
+#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 4)       // timing ablation 4: no operand reads
+            kf[i] = qf[0][ks];
+            (void)row;
+#else
+            kf[i] = *reinterpret_cast<const bf16x8*>(klds + row * (D * 2) + (((ks * 4 + g) ^ (row & KMASK)) << 4));
+#endif
+        }
+#pragma unroll
+        for (int i = 0; i < KS * NKT; ++i) {
+            const int ks = i / NKT, kt = i % NKT;
+#pragma unroll
+#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 8)       // timing ablation 8: no MFMAs (the reads stay)
+            asm volatile("" ::"v"(kf[i]));
+            (void)ks; (void)kt;
+#else
+            for (int qt = 0; qt < QT; ++qt)
+                s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[i], qf[qt][ks], s[qt][kt], 0, 0, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+        for (int i = 0; i < 16 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    // online softmax of the tile in `s` -> `pf` (same arithmetic as Core::tile)
+    SGLK_DEV void softmax(int key_base, const int (&limit)[QT], float scale_log2e, float logit_cap, int lane) {
+#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 1)     // timing ablation: no softmax arithmetic (wrong results)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int ss = 0; ss < NKT / 2; ++ss) {
+                u32x4 w;
+                w[0] = pack_bf16x2(s[qt][2 * ss][0], s[qt][2 * ss][1]);
+                w[1] = pack_bf16x2(s[qt][2 * ss][2], s[qt][2 * ss][3]);
+                w[2] = pack_bf16x2(s[qt][2 * ss + 1][0], s[qt][2 * ss + 1][1]);
+                w[3] = pack_bf16x2(s[qt][2 * ss + 1][2], s[qt][2 * ss + 1][3]);
+                pf[qt][ss] = __builtin_bit_cast(bf16x8, w);
+            }
+        return;
+#endif
+        int lim_min = limit[0] < limit[1] ? limit[0] : limit[1];
+        const bool masked = __any(key_base + NKT * 16 > lim_min);
+        const bool capped = __builtin_amdgcn_readfirstlane(logit_cap > 0.f);
+        constexpr float kRescaleThr = 8.0f;
+        const int g = lane >> 4;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float sc = scale_log2e;
+            if (capped) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = s[qt][kt][j] * scale_log2e * 0.6931471805599453f;
+                        s[qt][kt][j] = logit_cap * tanhf(x / logit_cap) * 1.4426950408889634f;
+                    }
+                sc = 1.f;
+            }
+            if (masked) {
+#pragma unroll
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = key_base + kt * 16 + g * 4 + j;
+                        s[qt][kt][j] = key < limit[qt] ? s[qt][kt][j] : -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[qt][kt][j]);
+            // the column's four lane groups: row swaps on the VALU (no LDS round trip -- this wave is alone on its SIMD's VALU
+            // during the slot, nothing would hide a ds_bpermute's latency)
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
+            mx *= sc;
+            float m_new = m[qt];
+            if (__any(mx > m[qt] + kRescaleThr)) {
+                m_new = fmaxf(m[qt], mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m[qt] - m_new);
+                l[qt] *= alpha;
+#pragma unroll
+                for (int t = 0; t < VT; ++t) o[qt][t] *= alpha;
+                m[qt] = m_new;
+            }
+            const float neg_m = (m_new == -INFINITY) ? 0.f : -m_new;
+            // packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction)
+            const f32x2 sc2 = {sc, sc}, nm2 = {neg_m, neg_m};
+            f32x2 ps = {0.f, 0.f};
+            float pr[NKT][4];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const f32x2 lo = {s[qt][kt][0], s[qt][kt][1]}, hi = {s[qt][kt][2], s[qt][kt][3]};
+                const f32x2 y0 = __builtin_elementwise_fma(lo, sc2, nm2), y1 = __builtin_elementwise_fma(hi, sc2, nm2);
+                const f32x2 e0 = {__builtin_amdgcn_exp2f(y0[0]), __builtin_amdgcn_exp2f(y0[1])};   // exp2(-inf) = 0 for masked keys
+                const f32x2 e1 = {__builtin_amdgcn_exp2f(y1[0]), __builtin_amdgcn_exp2f(y1[1])};
+                ps += e0;
+                ps += e1;
+                pr[kt][0] = e0[0]; pr[kt][1] = e0[1]; pr[kt][2] = e1[0]; pr[kt][3] = e1[1];
+            }
+            l[qt] += ps[0] + ps[1];
+#pragma unroll
+            for (int ss = 0; ss < NKT / 2; ++ss) {
+                u32x4 w;
+                w[0] = pack_bf16x2(pr[2 * ss][0], pr[2 * ss][1]);
+                w[1] = pack_bf16x2(pr[2 * ss][2], pr[2 * ss][3]);
+                w[2] = pack_bf16x2(pr[2 * ss + 1][0], pr[2 * ss + 1][1]);
+                w[3] = pack_bf16x2(pr[2 * ss + 1][2], pr[2 * ss + 1][3]);
+                pf[qt][ss] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+    }
+    // O^T += V^T . P  (operand reads eight ahead, as in qk)
+    SGLK_DEV void pv(const unsigned char* vlds, int lane) {
+        const int r = lane & 15, g = lane >> 4;
+        const int q = r >> 2, pp = r & 3;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x4 lo[VT * 2], hi[VT * 2];
+#pragma unroll
+        for (int i = 0; i < VT * 2; ++i) {
+            const int t = i >> 1, ss = i & 1;
+            const int row0 = ss * 32 + g * 4 + q;
+            const int row1 = row0 + 16;
+            const int col = t * 16 + pp * 4;
+            const int ch = col >> 3, sub = (col & 7) * 2;
+            const unsigned char* a0 = vlds + row0 * (DV * 2) + ((ch ^ vswz(row0)) << 4) + sub;
+            const unsigned char* a1 = vlds + row1 * (DV * 2) + ((ch ^ vswz(row1)) << 4) + sub;
+#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 4)
+            lo[i] = __builtin_bit_cast(s16x4, (uint2){(unsigned)i, 0u});
+            hi[i] = lo[i];
+            (void)a0; (void)a1;
+#else
+            lo[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+            hi[i] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+#endif
+        }
+#pragma unroll
+        for (int i = 0; i < VT * 2; ++i) {
+            const int t = i >> 1, ss = i & 1;
+            s16x8 vv;
+            vv[0] = lo[i][0]; vv[1] = lo[i][1]; vv[2] = lo[i][2]; vv[3] = lo[i][3];
+            vv[4] = hi[i][0]; vv[5] = hi[i][1]; vv[6] = hi[i][2]; vv[7] = hi[i][3];
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 8)
+            asm volatile("" ::"v"(vf));
+            (void)t; (void)ss;
+#else
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ss], o[qt][t], 0, 0, 0);
+#endif
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 0);
+#pragma unroll
+        for (int i = 0; i < 16 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    SGLK_DEV float column_sum(int qt) const {
+        float v = l[qt];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        return v;
+    }
+};
+
+// end of a slot: LDS writes of this wave have landed (lgkmcnt(0)); the staged global loads stay in flight across the barrier
+// (__syncthreads would wait for them -- a slot would then last at least one memory round trip)
+SGLK_DEV void slot_barrier_m() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+SGLK_DEV void slot_barrier_v() {             // ... and this wave's LDS-DMA halves have landed
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+#ifndef SGLK_PP_PRIO
+#define SGLK_PP_PRIO 2
+#endif
+template <int FORM>   // 0 = extend_attention_cpu, 1 = flash_attn_varlen_func (exact head dims, aligned rows)
+__global__ __launch_bounds__(512, 2) void extend_pp_kernel(const ExtendParams p) {
+    constexpr bool VARLEN = FORM != 0;
+    constexpr int D = 128, DV = 128, QT = 2, QB = 256, WQ = 32;
+    constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pp_lds[];   // K ring [3][KB], V ring [3][VB]
+    unsigned char* const kring = pp_lds;
+    unsigned char* const vring = pp_lds + 3 * KB;
+
+    const int lin = blockIdx.x;
+    const int nqblk = p.nqblk;
+    int b, h, qblk;
+    if (p.order & 2) { h = lin % p.HQ; b = (lin / p.HQ) % p.B; qblk = lin / (p.HQ * p.B); }
+    else { qblk = lin % nqblk; b = (lin / nqblk) % p.B; h = lin / (nqblk * p.B); }
+    int ext_len, prefix, ext_start, k_start = 0, n_keys;
+    if (VARLEN) {
+        ext_start = p.cu_q[b];
+        ext_len = p.cu_q[b + 1] - ext_start;
+        k_start = p.cu_k[b];
+        n_keys = p.cu_k[b + 1] - k_start;
+        prefix = 0;
+    } else {
+        ext_len = p.b_seq_len_extend[b];
+        prefix = (int)p.b_seq_len[b] - ext_len;
+        ext_start = p.b_start_loc_extend[b];
+        k_start = ext_start;
+        n_keys = prefix + ext_len;
+    }
+    const bool causal = !VARLEN || p.causal;
+    const int q0 = (nqblk - 1 - qblk) * QB;      // heaviest query blocks first
+    if (q0 >= ext_len) return;
+    const int64_t req = VARLEN ? 0 : p.b_req_idx[b];
+    const int kvh = h / (p.HQ / p.HKV);
+    const int kvh_buf = p.HBUF == p.HKV ? kvh : 0;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = wave >> 2;                    // 0: group A, 1: group B (one slot behind)
+    // the two waves of a SIMD take neighbouring 32-query slices, so that they see about the same number of tiles
+    const int qslot = ((wave & 3) << 1) | grp;
+    CorePP core;
+    core.init();
+    int limit[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qi = q0 + qslot * WQ + qt * 16 + (lane & 15);
+        const bool valid = qi < ext_len;
+        core.load_q(qt, valid ? p.q + (int64_t)(ext_start + qi) * p.q_s0 + (int64_t)h * p.q_s1 : nullptr, lane);
+        const int vis = causal ? (prefix + qi + 1 < n_keys ? prefix + qi + 1 : n_keys) : n_keys;
+        limit[qt] = valid ? vis : 0;
+    }
+    KvSource ks, vs;
+    const unsigned char* page = reinterpret_cast<const unsigned char*>(p.req_to_tokens) + req * p.rtt_stride * (p.rtt_is64 ? 8 : 4);
+    ks.buf = p.k_buf + (int64_t)kvh_buf * p.kb_s1; ks.buf_stride_tok = p.kb_s0; ks.page = page; ks.page_is64 = p.rtt_is64; ks.n_paged = prefix;
+    ks.ext = p.k_ext + (int64_t)k_start * p.ke_s0 + (int64_t)kvh * p.ke_s1; ks.ext_stride_tok = p.ke_s0;
+    vs = ks;
+    vs.buf = p.v_buf + (int64_t)kvh_buf * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
+    vs.ext = p.v_ext + (int64_t)k_start * p.ve_s0 + (int64_t)kvh * p.ve_s1; vs.ext_stride_tok = p.ve_s0;
+
+    const int q_last = (q0 + QB < ext_len ? q0 + QB : ext_len);
+    const int kv_end = causal ? (prefix + q_last < n_keys ? prefix + q_last : n_keys) : n_keys;
+    const float scale_log2e = p.sm_scale * 1.4426950408889634f;
+    const int nt = (kv_end + kKeys - 1) / kKeys;            // tiles of the workgroup (>= 1)
+    const int wave_q_last = (q0 + qslot * WQ + WQ < ext_len) ? q0 + qslot * WQ + WQ : ext_len;
+    const int wave_kv_end = causal ? (prefix + wave_q_last < n_keys ? prefix + wave_q_last : n_keys) : n_keys;
+    const int nt_w = q0 + qslot * WQ < ext_len ? (wave_kv_end + kKeys - 1) / kKeys : 0;   // tiles this wave's queries can see
+    auto nkeys = [&](int t) { const int r = kv_end - t * kKeys; return r < kKeys ? r : kKeys; };
+
+    // ---- prologue: K_0, K_1, V_0 by all threads (two halves per tile and thread group) ----
+    const int t256 = threadIdx.x & 255, wv = t256 >> 6;
+    HalfDma<D, FORM> kd;
+    HalfDma<DV, FORM, true> vd;
+    kd.prep(ks, 0, nkeys(0), grp, t256);
+    kd.issue(kring, grp, wv);
+    vd.prep(vs, 0, nkeys(0), grp, t256);
+    vd.issue(vring, grp, wv);
+    if (nt > 1) {
+        kd.prep(ks, kKeys, nkeys(1), grp, t256);
+        kd.issue(kring + KB, grp, wv);
+    }
+    // pointers of the halves that travel during V_t: K_{t+2}, V_{t+1}  (page lookups one slot before the DMA instructions: loads
+    // retire in order, a lookup issued behind DMA instructions could not be consumed before those have landed)
+    auto stage_prep = [&](int t) __attribute__((always_inline)) {
+        if (t + 2 < nt) kd.prep(ks, (t + 2) * kKeys, nkeys(t + 2), grp, t256);
+        if (t + 1 < nt) vd.prep(vs, (t + 1) * kKeys, nkeys(t + 1), grp, t256);
+    };
+    auto stage_issue = [&](int t) __attribute__((always_inline)) {
+        if (t + 2 < nt) kd.issue(kring + ((t + 2) % 3) * KB, grp, wv);
+        if (t + 1 < nt) vd.issue(vring + ((t + 1) % 3) * VB, grp, wv);
+    };
+    stage_prep(0);
+    slot_barrier_v();
+    if (grp == 1) slot_barrier_m();             // slot 0: group B idles
+    // slot: S_0
+    if (nt_w > 0) core.qk(kring, lane);
+    stage_issue(0);
+    slot_barrier_m();
+    for (int t = 0; t < nt; ++t) {
+        // ---- V_t ----
+        stage_prep(t + 1);
+        if (t < nt_w) core.softmax(t * kKeys, limit, scale_log2e, p.logit_cap, lane);
+        slot_barrier_v();                       // the halves issued one slot ago have landed
+        // ---- M_t ----
+        __builtin_amdgcn_s_setprio(SGLK_PP_PRIO);    // the matrix-slot wave wins the SIMD's issue arbitration (+2 %)
+#if !(defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 2))   // timing ablation 2: no matrix slot (wrong results)
+        if (t < nt_w) core.pv(vring + (t % 3) * VB, lane);
+        if (t + 1 < nt_w) core.qk(kring + ((t + 1) % 3) * KB, lane);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        stage_issue(t + 1);                     // behind the slot's last LDS read
+        slot_barrier_m();
+    }
+    if (grp == 0) slot_barrier_m();             // last slot: group A idles
+    // ---- normalise and store ----
+    const int g4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float lsum = core.column_sum(qt);
+        const int qi = q0 + qslot * WQ + qt * 16 + (lane & 15);
+        if (qi >= ext_len) continue;
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        unsigned short* orow = p.o + (int64_t)(ext_start + qi) * p.o_s0 + (int64_t)h * p.o_s1;
+#pragma unroll
+        for (int t = 0; t < DV / 16; ++t) {
+            const f32x4 v = core.o[qt][t] * inv;
+            uint2 w;
+            w.x = pack_bf16x2(v[0], v[1]);
+            w.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(orow + t * 16 + g4) = w;
         }
     }
 }
@@ -494,9 +978,6 @@ struct DecodeParams {
     int HQ, HKV, splits, logit_splits, v_alias;   // splits used / depth of the caller's scratch
     float sm_scale, logit_cap;
 };
-
-typedef const __attribute__((address_space(1))) void* dma_gptr_t;
-typedef __attribute__((address_space(3))) void* dma_lptr_t;
 
 // LDS-DMA staging of one 64-key tile (no registers, asynchronous): the image is written linearly, 1 KiB per wave
 // instruction, and the 16-byte-chunk swizzle is applied to the SOURCE address.  Rows past `nkeys` re-read the last valid
@@ -766,13 +1247,25 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
         const bool nw4 = knobs().attn_nw == 4; (void)wgs8;                                             \
         const int nw = nw4 ? 4 : 8;                                                                    \
         p.nqblk = (int)ceil_div(a->max_len_extend, nw * QT * 16);                                      \
-        const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;                                           \
+        p.pair = pair_blocks(p.nqblk, (int64_t)p.nqblk * a->B * a->HQ, p.n_cu, nw4 ? 0 : 1);           \
+        const int64_t wgs = (int64_t)(p.pair ? (p.nqblk + 1) / 2 : p.nqblk) * a->B * a->HQ;            \
         SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "extend_attention: too many workgroups");      \
         const dim3 grid((unsigned)wgs);                                                                \
         if (nw4) hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0, 4>), grid, dim3(256), 0, s, p); \
         else hipLaunchKernelGGL((extend_attention_kernel<DD, DDV, QT, 0, 8>), grid, dim3(512), 0, s, p);  \
         SGLK_CHECK_LAUNCH("extend_attention");                                                         \
         return SGLK_OK;                                                                                \
+    }
+    if (a->D == 128 && a->DV == 128 && knobs().attn_pp != 0 && knobs().attn_nw != 4) {   // two-phase form (SGLK_ATTN_PP=0: the form above)
+        p.nqblk = (int)ceil_div(a->max_len_extend, 256);
+        p.pair = 0;
+        const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;
+        SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "extend_attention: too many workgroups");
+        constexpr int kPpLds = 6 * kKeys * 128 * 2;
+        SGLK_ENSURE_DYN_LDS(extend_pp_kernel<0>, kPpLds, "extend_attention");
+        hipLaunchKernelGGL(extend_pp_kernel<0>, dim3((unsigned)wgs), dim3(512), kPpLds, s, p);
+        SGLK_CHECK_LAUNCH("extend_attention");
+        return SGLK_OK;
     }
     EXT_CASE(128, 128)
     EXT_CASE(128, 96)
@@ -814,10 +1307,20 @@ extern "C" int sglk_flash_attn_varlen(const sglk_flash_attn_varlen_args* a, void
     const bool exact = a->D == Dp && a->DV == DVp && p.v_aligned;
     p.B = a->B; p.n_cu = attn_cus(); p.order = attn_order(2);
     p.nqblk = (int)ceil_div(a->max_seqlen_q, 8 * 2 * 16);
-    const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;
+    p.pair = pair_blocks(p.nqblk, (int64_t)p.nqblk * a->B * a->HQ, p.n_cu, a->causal);
+    const int64_t wgs = (int64_t)(p.pair ? (p.nqblk + 1) / 2 : p.nqblk) * a->B * a->HQ;
     SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "flash_attn_varlen: too many workgroups");
     const dim3 block(512);
     hipStream_t s = (hipStream_t)stream;
+    if (exact && Dp == 128 && DVp == 128 && knobs().attn_pp != 0) {   // two-phase form
+        p.pair = 0;
+        const int64_t wgs2 = (int64_t)p.nqblk * a->B * a->HQ;
+        constexpr int kPpLds = 6 * kKeys * 128 * 2;
+        SGLK_ENSURE_DYN_LDS(extend_pp_kernel<1>, kPpLds, "flash_attn_varlen");
+        hipLaunchKernelGGL(extend_pp_kernel<1>, dim3((unsigned)wgs2), block, kPpLds, s, p);
+        SGLK_CHECK_LAUNCH("flash_attn_varlen");
+        return SGLK_OK;
+    }
 #define FA_CASE(DD, DDV)                                                                               \
     if (Dp == DD && DVp == DDV) {                                                                      \
         const dim3 grid((unsigned)wgs);                                                                \

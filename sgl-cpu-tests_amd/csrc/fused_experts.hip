@@ -253,8 +253,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     // expert.
     const bool split_tails = tuned && tile_m == 256 && K % 256 == 0 && N % 256 == 0 && K <= 4096 && N <= 4096 &&
                              (int64_t)M * topk < (int64_t)640 * E && !(a->flags & SGLK_MOE_FP8_ACT) &&
-                             (tail_knob == 1 || (tail_knob != 0 && have_aux));
-    const bool side = split_tails && tail_knob != 1 && have_aux;
+                             (tail_knob == 1 || tail_knob == 2 || (tail_knob != 0 && have_aux));
+    const bool side = split_tails && tail_knob != 1 && tail_knob != 2 && have_aux;
     int* tile_info_b = (int*)(ws + w.tile_info_b);
     int* num_tiles_b = (int*)(ws + w.num_tiles_b);
     mark(0);
@@ -276,7 +276,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     if (!routed_and_aligned)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
-                                    w.sorted_slot - w.align_ws, stream);
+                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets));
     if (rc != SGLK_OK) return rc;
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
@@ -493,17 +493,16 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g1.out = ic1;
         g1.out_stride = N;
         g1.topk_weights = nullptr;
-        if (tile_m == 256) {   // per-XCD tile tickets of the two persistent launches (8 counters each), zeroed per call
-            int* tickets = (int*)(ws + w.tickets);
-            if (hipMemsetAsync(tickets, 0, 16 * sizeof(int), s) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: ticket reset failed");
-            g1.tickets = tickets;
-        }
+        // per-XCD tile tickets of the two persistent launches (8 counters each), zeroed per call by moe_align's last launch
+        if (tile_m == 256) g1.tickets = (int*)(ws + w.tickets);
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) g1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
         hipEvent_t ev_join = nullptr;
+        bool tails_last = false;     // SGLK_TAIL_SPLIT=2: the tails on the caller's stream, BEHIND the two big launches
+        MoeGemmParams tl1{}, tl2{};
+        const int tails_max = E < max_tiles ? E : max_tiles;
         if (split_tails) {
-            const int tails_max = E < max_tiles ? E : max_tiles;
             MoeGemmParams t1 = g1;
             t1.tile_info = (const int4*)tile_info_b;
             t1.num_tiles = num_tiles_b;
@@ -537,10 +536,16 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
             }
             // with a side stream both tail launches go out here, before the big GEMM-1, and overlap it and GEMM-2; on the
             // caller's stream they simply run first
-            rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, t1, tails_max, ts);
-            if (rc != SGLK_OK) return rc;
-            rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
-            if (rc != SGLK_OK) return rc;
+            tails_last = !side && tail_knob == 2;
+            if (tails_last) {
+                tl1 = t1;
+                tl2 = t2;
+            } else {
+                rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, t1, tails_max, ts);
+                if (rc != SGLK_OK) return rc;
+                rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
+                if (rc != SGLK_OK) return rc;
+            }
             if (side && hipEventRecord(ev_join, ts) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream record failed");
         }
         rc = tile_m == 256 ? launch_moe_gemm_fp8w_256i(MODE_GATE_UP, g1, max_tiles, s)
@@ -582,6 +587,12 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
                                                     : launch_moe_gemm_fp8w_mid(MODE_DOWN, g2, max_tiles, s))
                                       : launch_moe_gemm_fp8w(MODE_DOWN, g2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
+        if (tails_last) {
+            rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, tl1, tails_max, s);
+            if (rc != SGLK_OK) return rc;
+            rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, tl2, tails_max, s);
+            if (rc != SGLK_OK) return rc;
+        }
         // join: the combine needs the tail tiles' rows of ic2 too
         if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: side-stream join failed");
         mark(3);

@@ -251,7 +251,8 @@ int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipSt
 // (tail_max <= 0: exactly sglk_moe_align)
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,
                            int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, int32_t tail_max,
-                           int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream);
+                           int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream,
+                           int32_t* zero16 = nullptr);   // zero16: 16 ints cleared by the same launches (tile tickets)
 
 // the routed experts' per-slot rows, to be summed (valid slots, ascending) and scaled inside another kernel's epilogue
 struct MoeSlotAddend {
