@@ -43,13 +43,6 @@ struct KvSource {
     int n_paged;
     const unsigned short* ext;
     int64_t ext_stride_tok;
-    // decode only: the token written by THIS call is taken from the caller's key / value rows instead of the cache, so that
-    // the cache write needs no launch of its own in front of the attention.  new_tok = its cache slot (-1: none); elements
-    // below new_lo_elems come from new_row_lo (MLA alias: the cache row is [value | key[DV:]] after both writes)
-    int64_t new_tok;
-    const unsigned short* new_row;
-    const unsigned short* new_row_lo;
-    int new_lo_elems;
 };
 
 SGLK_DEV const unsigned short* kv_row(const KvSource& s, int p) {
@@ -984,12 +977,6 @@ struct DecodeParams {
     const int64_t* b_seq_len;
     int HQ, HKV, splits, logit_splits, v_alias;   // splits used / depth of the caller's scratch
     float sm_scale, logit_cap;
-    // the token of this call: written to the cache by the split-0 workgroups, read by everybody from key / value directly
-    unsigned short *k_cache, *v_cache;
-    const unsigned short *key, *value;
-    int64_t key_s0, key_s1, val_s0, val_s1;
-    const void* loc;
-    int loc_is64;
 };
 
 // LDS-DMA staging of one 64-key tile (no registers, asynchronous): the image is written linearly, 1 KiB per wave
@@ -1020,9 +1007,7 @@ struct TileDma {
         for (int i = 0; i < N; ++i) {
             const int c = i * THREADS + wave * 64 + lane;
             const int row = c / CH, slot = c - row * CH;
-            const int e0 = (slot ^ (row & MASK)) << 3;
-            const unsigned short* fresh = e0 < src.new_lo_elems ? src.new_row_lo : src.new_row;
-            const unsigned short* g = ((int64_t)tok[i] == src.new_tok ? fresh : src.buf + (int64_t)tok[i] * src.buf_stride_tok) + e0;
+            const unsigned short* g = src.buf + (int64_t)tok[i] * src.buf_stride_tok + ((slot ^ (row & MASK)) << 3);
             __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * THREADS + wave * 64) * 16), 16, 0, 0);
         }
     }
@@ -1040,11 +1025,7 @@ struct TileDma {
                     const int c = i * THREADS + wave * 64 + lane;        // linear chunk of the image this lane fills
                     const int row = c / CH, slot = c - row * CH;
                     const int rr = row < nkeys ? row : nkeys - 1;
-                    const int e0 = (slot ^ (row & MASK)) << 3;
-                    const int64_t tk = src.page_is64 ? reinterpret_cast<const int64_t*>(src.page)[p0 + rr]
-                                                     : (int64_t)reinterpret_cast<const int*>(src.page)[p0 + rr];
-                    const unsigned short* fresh = e0 < src.new_lo_elems ? src.new_row_lo : src.new_row;
-                    g[j] = (tk == src.new_tok ? fresh : src.buf + tk * src.buf_stride_tok) + e0;
+                    g[j] = kv_row_paged(src, p0 + rr) + ((slot ^ (row & MASK)) << 3);
                 }
             }
 #pragma unroll
@@ -1100,25 +1081,8 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
     const unsigned char* page = reinterpret_cast<const unsigned char*>(p.req_to_token) + req * p.rtt_stride * (p.rtt_is64 ? 8 : 4);
     ks.buf = p.k_buf + (int64_t)kvh * p.kb_s1; ks.buf_stride_tok = p.kb_s0; ks.page = page; ks.page_is64 = p.rtt_is64;
     ks.n_paged = seq_len; ks.ext = nullptr; ks.ext_stride_tok = 0;
-    const int64_t new_tok = !p.loc ? -1 : (p.loc_is64 ? reinterpret_cast<const int64_t*>(p.loc)[b] : (int64_t)reinterpret_cast<const int*>(p.loc)[b]);
-    const unsigned short* key_row = p.key + (int64_t)b * p.key_s0 + (int64_t)kvh * p.key_s1;
-    const unsigned short* val_row = p.value + (int64_t)b * p.val_s0 + (int64_t)kvh * p.val_s1;
-    ks.new_tok = new_tok;
-    ks.new_row = key_row;
-    ks.new_row_lo = V_ALIAS ? val_row : key_row;          // alias: the cache row ends up as [value | key[DV:]]
-    ks.new_lo_elems = V_ALIAS ? DV : 0;
     vs = ks;
     vs.buf = p.v_buf + (int64_t)kvh * p.vb_s1; vs.buf_stride_tok = p.vb_s0;
-    vs.new_row = val_row; vs.new_row_lo = val_row; vs.new_lo_elems = 0;
-    // k_buffer[loc[b]] = key[b]; v_buffer[loc[b]] = value[b] (bit-exact copies, K first like the reference:
-    // /root/reference/test_mla.py:27,174-175).  Nobody in this launch reads that cache row.
-    if (split == 0 && p.loc) {
-        unsigned short* kc = p.k_cache + new_tok * p.kb_s0 + (int64_t)kvh * p.kb_s1;
-        unsigned short* vc = p.v_cache + new_tok * p.vb_s0 + (int64_t)kvh * p.vb_s1;
-        for (int c = threadIdx.x; c < D; c += 256 * KH) kc[c] = key_row[c];
-        if (V_ALIAS) __syncthreads();                    // same storage: the value columns must land after the key's
-        for (int c = threadIdx.x; c < DV; c += 256 * KH) vc[c] = val_row[c];
-    }
     const float scale_log2e = p.sm_scale * 1.4426950408889634f;
 
     const int ntiles = (k_end - k_begin + kKeys - 1) / kKeys;
@@ -1389,28 +1353,18 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
                                a->v_buffer_stride[0], a->v_buffer_stride[1]};
     for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "decode_attention: q/k/v strides must be multiples of 8 elements");
     hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(kv_cache_write_kernel, dim3((unsigned)a->B, (unsigned)a->HKV), dim3(256), 0, s,
+                       (unsigned short*)a->k_buffer, a->k_buffer_stride[0], a->k_buffer_stride[1], (unsigned short*)a->v_buffer,
+                       a->v_buffer_stride[0], a->v_buffer_stride[1], (const unsigned short*)a->key, a->key_stride[0],
+                       a->key_stride[1], (const unsigned short*)a->value, a->value_stride[0], a->value_stride[1], a->loc,
+                       a->loc_is64, a->B, a->HKV, a->D, a->DV);
+    SGLK_CHECK_LAUNCH("decode_attention(cache write)");
     DecodeParams p{};
     p.q = (const unsigned short*)a->q; p.k_buf = (const unsigned short*)a->k_buffer; p.v_buf = (const unsigned short*)a->v_buffer;
     p.q_s0 = a->q_stride[0]; p.q_s1 = a->q_stride[1]; p.kb_s0 = a->k_buffer_stride[0]; p.kb_s1 = a->k_buffer_stride[1];
     p.vb_s0 = a->v_buffer_stride[0]; p.vb_s1 = a->v_buffer_stride[1]; p.logits = a->attn_logits;
     p.req_to_token = a->req_to_token; p.rtt_stride = a->req_to_token_stride; p.rtt_is64 = a->req_to_token_is64;
     p.b_req_idx = a->b_req_idx; p.b_seq_len = a->b_seq_len; p.HQ = a->HQ; p.HKV = a->HKV;
-    p.k_cache = (unsigned short*)a->k_buffer; p.v_cache = (unsigned short*)a->v_buffer;
-    p.key = (const unsigned short*)a->key; p.value = (const unsigned short*)a->value;
-    p.key_s0 = a->key_stride[0]; p.key_s1 = a->key_stride[1]; p.val_s0 = a->value_stride[0]; p.val_s1 = a->value_stride[1];
-    p.loc = a->loc; p.loc_is64 = a->loc_is64;
-    // the new token's rows are read by 16-byte DMA: rows that are not 16-byte aligned take the separate cache-write launch
-    const bool fresh_ok = a->key_stride[0] % 8 == 0 && a->key_stride[1] % 8 == 0 && a->value_stride[0] % 8 == 0 &&
-                          a->value_stride[1] % 8 == 0 && ((uintptr_t)a->key % 16) == 0 && ((uintptr_t)a->value % 16) == 0;
-    if (!fresh_ok) {
-        hipLaunchKernelGGL(kv_cache_write_kernel, dim3((unsigned)a->B, (unsigned)a->HKV), dim3(256), 0, s,
-                           (unsigned short*)a->k_buffer, a->k_buffer_stride[0], a->k_buffer_stride[1], (unsigned short*)a->v_buffer,
-                           a->v_buffer_stride[0], a->v_buffer_stride[1], (const unsigned short*)a->key, a->key_stride[0],
-                           a->key_stride[1], (const unsigned short*)a->value, a->value_stride[0], a->value_stride[1], a->loc,
-                           a->loc_is64, a->B, a->HKV, a->D, a->DV);
-        SGLK_CHECK_LAUNCH("decode_attention(cache write)");
-        p.loc = nullptr;
-    }
     // Splits actually used (<= the caller's scratch depth; the merge reads only these): every (request, kv head, split) is one
     // workgroup and a wide-head (D >= 256) workgroup owns a CU, so more workgroups than CUs run in ROUNDS that each pay the
     // prologue (page lookups, first tile) again.  Use the most splits that still fit one round (SGLK_DEC_SPLITS=n forces n, -1 =
