@@ -311,9 +311,14 @@ int sglk_ep_reduce_rows(const void* rows, int64_t rows_stride, const int32_t* ta
  * (+ bias f32 [N]).  wq uint8 [N][K/2], element 2i of a row in the low nibble of byte i (E2M1: sign, 2-bit exponent,
  * 1-bit mantissa -> 0, 0.5, 1, 1.5, 2, 3, 4, 6); scales uint8 E8M0 (2^(s-127)) per 32 consecutive k: [N][K/32] row-major,
  * or with scale_packed != 0 the order convert_scale_packed returns ([N/32][K/32][32], test_mxfp4.py:186).  The weights
- * are expanded to bf16 exactly and multiplied on the bf16 matrix cores with fp32 accumulation (W4A16, like the reference;
- * activations are never quantised).  K % 32 == 0; scale_packed needs N % 32 == 0.  Workspace:
- * sglk_scaled_mm_workspace_bytes(M, N, K, SGLK_W_BF16, 0). */
+ * are never dequantised to memory and the activations are never quantised (W4A16, like the reference):
+ *   M >= 64, N % 128 == 0, K % 256 == 0: v_mfma_scale_f32_32x32x64_f8f6f4 with the E2M1 weights and their E8M0 block scales
+ *     as stored; the bf16 activations enter as two e4m3 terms (exact for elements within 2^13 of their 128-block's maximum);
+ *   otherwise: exact expansion to bf16 in registers, bf16 matrix cores.
+ * fp32 accumulation, one bf16 rounding.  K % 32 == 0; scale_packed needs N % 32 == 0.  Workspace:
+ * sglk_mxfp4_workspace_bytes(M, N, K) (with only sglk_scaled_mm_workspace_bytes(M, N, K, SGLK_W_BF16, 0) bytes the second
+ * form runs for every shape). */
+size_t sglk_mxfp4_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void* wq, const void* scales, int32_t scale_packed,
                          const float* bias, void* out, int64_t out_stride, int32_t M, int32_t N, int32_t K,
                          void* workspace, size_t workspace_bytes, void* stream);

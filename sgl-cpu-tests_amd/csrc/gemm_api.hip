@@ -634,6 +634,12 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     return launch_gemm_generic(GG_PLAIN, g, tiles, s);
 }
 
+extern "C" size_t sglk_mxfp4_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+    if (M < 0 || N <= 0 || K <= 0) return 0;
+    const size_t dense = plan_dense(M, N, K, false, false).total, native = mxfp4_native_workspace_bytes(M, N, K);
+    return dense > native ? dense : native;
+}
+
 extern "C" int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void* wq, const void* scales, int32_t scale_packed,
                                     const float* bias, void* out, int64_t out_stride, int32_t M, int32_t N, int32_t K,
                                     void* workspace, size_t workspace_bytes, void* stream) {
@@ -649,6 +655,10 @@ extern "C" int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void*
                  workspace_bytes, w.total);
     if (M == 0) return SGLK_OK;
     hipStream_t s = (hipStream_t)stream;
+    // M >= 64 and tileable shapes: the fp4 weights as stored on the block-scaled matrix cores (gemm_mxfp4.hip); a caller that
+    // sized the workspace with sglk_scaled_mm_workspace_bytes only (v1) stays on the bf16 expansion below
+    if (mxfp4_native_ok(M, N, K, x, x_stride, wq, out, out_stride) && workspace_bytes >= mxfp4_native_workspace_bytes(M, N, K))
+        return launch_gemm_mxfp4_native(x, x_stride, wq, scales, scale_packed, bias, out, out_stride, M, N, K, workspace, s);
     unsigned char* ws = (unsigned char*)workspace;
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);

@@ -19,40 +19,12 @@
 // through a ring of THREE 48-KiB LDS buffers (X 32 KiB + W 16 KiB) filled by LDS-DMA; 16 MFMAs per wave and stage.
 #include "knobs.h"
 #include "moe_internal.h"
+#include "fp8_split.h"
 
 namespace sglk {
 
 typedef __attribute__((address_space(3))) void* lptr_sp_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-
-SGLK_DEV int sp_e8m0_for_amax(float amax) {   // as e8m0_for_amax of moe_gemm_a8.hip, floor 5 so that the lo scale (sb - 4) >= 1
-    const unsigned u = __float_as_uint(amax);
-    int sb = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
-    sb = sb < 5 ? 5 : (sb > 253 ? 253 : sb);
-    return sb;
-}
-SGLK_DEV float sp_pow2(int e) { return __uint_as_float((unsigned)e << 23); }   // 2^(e - 127), 1 <= e <= 254
-
-// (hi, lo) of eight fp32 values with block scale byte sb: two dwords of e4m3 each
-SGLK_DEV void split8(const float* v, int sb, unsigned* hi, unsigned* lo) {
-    const float inv = sp_pow2(254 - sb), s = sp_pow2(sb), inv_lo = sp_pow2(254 - sb + 4);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int h = 0;
-        h = __builtin_amdgcn_cvt_pk_fp8_f32(v[q * 4 + 0] * inv, v[q * 4 + 1] * inv, h, false);
-        h = __builtin_amdgcn_cvt_pk_fp8_f32(v[q * 4 + 2] * inv, v[q * 4 + 3] * inv, h, true);
-        float r[4];   // the byte selector of the conversion must be a literal
-        r[0] = (v[q * 4 + 0] - __builtin_amdgcn_cvt_f32_fp8(h, 0) * s) * inv_lo;
-        r[1] = (v[q * 4 + 1] - __builtin_amdgcn_cvt_f32_fp8(h, 1) * s) * inv_lo;
-        r[2] = (v[q * 4 + 2] - __builtin_amdgcn_cvt_f32_fp8(h, 2) * s) * inv_lo;
-        r[3] = (v[q * 4 + 3] - __builtin_amdgcn_cvt_f32_fp8(h, 3) * s) * inv_lo;
-        int l = 0;
-        l = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], l, false);
-        l = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], l, true);
-        hi[q] = (unsigned)h;
-        lo[q] = (unsigned)l;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // hidden [rows][cols] bf16 -> q [rows][2 * cols] ([hi 64 | lo 64] per 64 group, packed-tile k order) + one E8M0 byte per

@@ -247,6 +247,12 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
 // DOWN with two neighbouring column tiles per workgroup (p.n_tiles = output columns / 256; reduction % 256 == 0)
 int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
+// native MX-fp4 GEMM (gemm_mxfp4.hip): fp4 weights as stored on the block-scaled matrix cores, activations as two e4m3 terms
+size_t mxfp4_native_workspace_bytes(int M, int N, int K);
+bool mxfp4_native_ok(int M, int N, int K, const void* x, int64_t x_stride, const void* wq, const void* out, int64_t out_stride);
+int launch_gemm_mxfp4_native(const void* x, int64_t x_stride, const void* wq, const void* scales, int scale_packed, const float* bias,
+                             void* out, int64_t out_stride, int M, int N, int K, void* workspace, hipStream_t stream);
+
 // moe_align with a second tile table: an expert's last tile lands in tile_info_b when it has at most tail_max rows
 // (tail_max <= 0: exactly sglk_moe_align)
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,

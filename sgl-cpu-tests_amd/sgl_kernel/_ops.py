@@ -913,7 +913,7 @@ def mxfp4_scaled_mm_cpu(x, weight, scale, bias, is_vnni):
     b = bias.contiguous() if bias is not None else None
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     L = _lib.lib()
-    ws = _workspace(L.sglk_scaled_mm_workspace_bytes(M, N, K, _lib.W_BF16, 0), x.device)
+    ws = _workspace(L.sglk_mxfp4_workspace_bytes(M, N, K), x.device)
     _lib.check(L.sglk_mxfp4_scaled_mm(_ptr(x), x.stride(0), _ptr(w), _ptr(sc), 1 if (is_vnni and N % 32 == 0) else 0,
                                       _ptr(b) if b is not None else None, _ptr(out), out.stride(0), M, N, K, _ptr(ws),
                                       ws.numel(), _stream(x)), "mxfp4_scaled_mm_cpu")

@@ -50,6 +50,49 @@ def test_mxfp4_expansion_is_exact(ops):
     assert torch.equal(out.float().cpu(), ogemm.mxfp4_dequant(wq, ws).t())
 
 
+@pytest.mark.parametrize("M,N,K,kind,has_bias", [(64, 128, 256, "wide", False), (128, 512, 2048, "raw", True), (1000, 384, 1024, "wide", True),
+                                                 (200, 256, 768, "quant", False)])
+def test_mxfp4_native_fp4_mfma_path(ops, knob, M, N, K, kind, has_bias):
+    """M >= 64, N % 128 == 0, K % 256 == 0 run on v_mfma_scale_f32_32x32x64_f8f6f4 with the E2M1 weights and E8M0 scales as
+    stored (csrc/gemm_mxfp4.hip; activations as two e4m3 terms).  Same contract as the expansion path: the reference predicate
+    against the fp32 oracle (/root/reference/test_mxfp4.py:166-170), relative RMS < 4e-3, both scale layouts identical bits, and
+    close to the bf16-expansion path (SGLK_MXFP4_NATIVE=0) -- both carry exact products and differ only in summation order."""
+    inp = recipes.mxfp4_inputs(M, N, K, kind, has_bias, 9800 + M, ogemm.mxfp4_quantize)
+    a, wq, ws = inp["a"].cuda(), inp["wq"].cuda(), inp["ws"].cuda()
+    bias = inp["bias"].cuda() if has_bias else None
+    knob(SGLK_MXFP4_NATIVE=1)            # these shapes have too few tiles to be routed there by default
+    out = ops.mxfp4_scaled_mm_cpu(a, wq, ws, bias, False)
+    ref32 = ogemm.mxfp4_scaled_mm(inp["a"], inp["wq"], inp["ws"], inp["bias"])
+    assert torch.allclose(ref32.bfloat16(), out.cpu(), rtol=1e-2, atol=1e-2)
+    err = (out.float().cpu() - ref32).norm() / ref32.norm()
+    assert err < 4e-3, f"relative RMS error {err:.2e}"
+    assert torch.equal(out, ops.mxfp4_scaled_mm_cpu(a, ops.convert_weight_packed(wq), ops.convert_scale_packed(ws), bias, True))
+    knob(SGLK_MXFP4_NATIVE=0)
+    exp = ops.mxfp4_scaled_mm_cpu(a, wq, ws, bias, False)
+    d = (out.float() - exp.float()).norm() / exp.float().norm()
+    assert d < 3e-3, f"native vs expansion path {d:.2e}"
+
+
+def test_mxfp4_native_path_is_exact_on_identity(ops, knob):
+    """x = identity through the native path (256 rows): every output is ONE exact product -> the dequantised weights bit for bit,
+    for every nibble, a spread of scales, and both lane halves / chunks of the operand layout."""
+    N, K = 256, 512
+    g = torch.Generator().manual_seed(9711)
+    wq = torch.randint(0, 256, (N, K // 2), generator=g, dtype=torch.uint8)
+    ws = torch.randint(100, 140, (N, K // 32), generator=g, dtype=torch.uint8)
+    eye = torch.eye(K, dtype=torch.bfloat16, device="cuda")
+    knob(SGLK_MXFP4_NATIVE=1)
+    out = ops.mxfp4_scaled_mm_cpu(eye, wq.cuda(), ws.cuda(), None, False)
+    assert torch.equal(out.float().cpu(), ogemm.mxfp4_dequant(wq, ws).t())
+    # and with activations that are not powers of two: x = 1.375 * permutation (hi + lo both in use), scaled rows
+    perm = torch.randperm(K, generator=g)
+    x = torch.zeros(K, K)
+    x[torch.arange(K), perm] = 1.375
+    out = ops.mxfp4_scaled_mm_cpu(x.bfloat16().cuda(), wq.cuda(), ws.cuda(), None, False)
+    want = (1.375 * ogemm.mxfp4_dequant(wq, ws).t()[perm]).bfloat16()
+    assert torch.equal(out.cpu(), want)
+
+
 def test_mxfp4_rejects_bad_arguments(ops):
     x = torch.zeros(2, 64, dtype=torch.bfloat16, device="cuda")
     wq = torch.zeros(32, 32, dtype=torch.uint8, device="cuda")

@@ -308,10 +308,12 @@ def bench_block():
 
 
 def bench_mxfp4():
-    """mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py): W4A16, weights expanded to bf16 in the loader.  Small M is bound
-    by the weight bytes (N*K/2 + scales), large M by the bf16 matrix cores; bmm_cpu rides along (test_bmm_fp8.py:131-132)."""
+    """mxfp4_scaled_mm_cpu (/root/reference/test_mxfp4.py): W4A16.  Small M: weights expanded to bf16 in the generic engine's
+    loader, bound by the weight bytes (N*K/2 + scales); large M: the fp4 weights as stored on the block-scaled matrix cores
+    (gemm_mxfp4.hip), priced against the bf16 roof (two e4m3 terms per activation = the bf16 rate); bmm_cpu rides along
+    (test_bmm_fp8.py:131-132)."""
     g = torch.Generator(device="cuda").manual_seed(4)
-    for (M, N, K) in ((1, 4096, 4096), (16, 4096, 4096), (128, 4096, 4096), (1024, 12288, 2048)):
+    for (M, N, K) in ((1, 4096, 4096), (16, 4096, 4096), (128, 4096, 4096), (1024, 12288, 2048), (4096, 4096, 4096)):
         x = (torch.randn(M, K, device="cuda", generator=g) / 10).bfloat16()
         wq = torch.randint(0, 256, (N, K // 2), device="cuda", generator=g, dtype=torch.uint8)
         ws = torch.randint(120, 128, (N, K // 32), device="cuda", generator=g, dtype=torch.uint8)

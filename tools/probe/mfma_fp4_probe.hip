@@ -101,7 +101,8 @@ int main() {
             const int r = l & 31, h = l >> 5;
             for (int j = 0; j < 32; ++j) {
                 const int sh = 8 * ((j / 2) & 3) + 4 * ((j & 1) ^ (lo ? 0 : 1));
-                ha[l * 8 + j / 8] |= (unsigned)Acode[r][32 * h + j] << sh;
+                // nibble j of the lane: chunk j / 16, k (in the labelling of the e4m3 B operand above) = 32 (j / 16) + 16 h + j % 16
+                ha[l * 8 + j / 8] |= (unsigned)Acode[r][32 * (j / 16) + 16 * h + (j % 16)] << sh;
             }
         }
         run();
@@ -113,7 +114,7 @@ int main() {
                 for (int k = 0; k < 64; ++k) d += 0.5 * A2[i][k] * B[k][j];
                 bad += (double)C0[i][j] != d;
             }
-        printf("layout: lane (r,h) nibble j = k 32h+j, %s nibble first: %d of 1024 outputs differ\n", lo ? "low" : "high", bad);
+        printf("layout: lane (r,h) nibble j = k 32(j/16)+16h+j%%16, %s nibble first: %d of 1024 outputs differ\n", lo ? "low" : "high", bad);
         if (bad == 0) { good_lo = lo; break; }
     }
     if (good_lo < 0) { printf("no layout hypothesis matched\n"); return 0; }
