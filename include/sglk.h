@@ -333,6 +333,48 @@ int sglk_per_token_quant_int8_floor(const void* x, int64_t x_stride, void* q, in
                                     int64_t rows, int32_t cols, float floor, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * qkv_proj_with_rope(hidden_states, q_a_proj_weight, q_b_proj_weight, kv_a_proj_weight, w_kc, q_a_layernorm_weight,
+ *                    kv_a_layernorm_weight, positions, cos_sin_cache, eps, use_int8_w8a8, use_fp8_w8a16, q_a_proj_scale,
+ *                    q_b_proj_scale, kv_a_proj_scale, is_vnni, block_size)            /root/reference/test_absorb.py:133-147,184-186
+ * in one call (oracles native_torch test_absorb.py:65-87, native_torch_int8 :89-131): the three projections (bf16, fp8 W8A16 with
+ * block scales, or int8 W8A8 with per-token activation quantisation, floor 1e-7), the two RMSNorms, the per-head product with
+ * w_kc [H][kv_lora][nope], GPT-J rotary embedding of the rope parts.  Every intermediate is rounded to bf16 where the oracle
+ * rounds.  Outputs: q_input [B][H][kv_lora + rope], k_input [B][1][kv_lora + rope], v_input [B][1][kv_lora] (bf16; strides in
+ * elements).  packed_*: the weight is in sglk_pack_weight order.  Intermediates live in the caller's workspace.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* hidden;          /* [B][hidden_size] bf16 */
+    int64_t hidden_stride;
+    int32_t B, hidden_size;
+    const void *q_a_w, *q_b_w, *kv_a_w;              /* [q_lora][hidden], [H*(nope+rope)][q_lora], [kv_lora+rope][hidden] */
+    const float *q_a_scale, *q_b_scale, *kv_a_scale; /* fp8: block scales; int8: per output row; bf16: NULL */
+    int32_t wtype;                                   /* SGLK_W_BF16 / SGLK_W_FP8_E4M3 / SGLK_W_INT8 */
+    int32_t packed_q_a, packed_q_b, packed_kv_a;
+    int32_t block_n, block_k;                        /* fp8 */
+    const void* w_kc;                                /* [H][kv_lora][nope] bf16 */
+    int32_t w_kc_packed;
+    const void *q_a_ln, *kv_a_ln;                    /* RMSNorm weights bf16 [q_lora], [kv_lora] */
+    float eps;
+    const void* positions;                           /* [B] int32 / int64 */
+    int32_t positions_is64;
+    const void* cos_sin_cache;                       /* [max_pos][rope] bf16 */
+    int64_t cache_stride;
+    int32_t H, q_lora, kv_lora, nope, rope;
+    void* q_input;
+    int64_t q_stride_b, q_stride_h;
+    void* k_input;
+    int64_t k_stride_b;
+    void* v_input;
+    int64_t v_stride_b;
+    void* workspace;
+    size_t workspace_bytes;
+} sglk_qkv_proj_args;
+
+size_t sglk_qkv_proj_workspace_bytes(int32_t B, int32_t hidden_size, int32_t H, int32_t q_lora, int32_t kv_lora, int32_t nope,
+                                     int32_t rope, int32_t wtype);
+int sglk_qkv_proj_with_rope(const sglk_qkv_proj_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Pieces of qkv_proj_with_rope (/root/reference/test_absorb.py:133-147; oracle native_torch :65-87) that are neither a
  * GEMM nor an RMSNorm; the Python layer composes the operator from these, sglk_scaled_mm and sglk_rmsnorm.
  *   bmm_heads  out[b][h][oc] = sum_ic x[b][h][ic] * w[h][oc][ic]   (bf16, fp32 accumulation; w [H][OC][IC] row-major or

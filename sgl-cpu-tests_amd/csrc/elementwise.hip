@@ -90,13 +90,15 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(unsigned short* __restrict
                                                       const unsigned short* __restrict__ x, int64_t x_stride,
                                                       unsigned short* __restrict__ residual, int64_t res_stride,
                                                       const unsigned short* __restrict__ w, int64_t rows, int h,
-                                                      float eps) {
+                                                      float eps, unsigned short* __restrict__ out2 = nullptr,
+                                                      int64_t out2_stride = 0) {   // out2: a second copy of the result rows
     __shared__ float red[4];
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];   // FUSED: the fp32 sum of the row
     const bool vec = (h % 8 == 0) && (x_stride % 8 == 0) && (out_stride % 8 == 0) && (!FUSED || res_stride % 8 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(w) & 15) == 0) &&
-                     (!FUSED || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+                     (!FUSED || (reinterpret_cast<uintptr_t>(residual) & 15) == 0) &&
+                     (!out2 || (out2_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(out2) & 15) == 0));
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const unsigned short* xr = x + row * x_stride;
         unsigned short* orow = out + row * out_stride;
@@ -141,12 +143,16 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(unsigned short* __restrict
                 unpack8<F16>(*reinterpret_cast<const uint4*>(w + c), wv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = round_io<F16>(f[j] * inv) * wv[j];
-                *reinterpret_cast<uint4*>(orow + c) = pack8<F16>(o);
+                const uint4 packed = pack8<F16>(o);
+                *reinterpret_cast<uint4*>(orow + c) = packed;
+                if (out2) *reinterpret_cast<uint4*>(out2 + row * out2_stride + c) = packed;
             }
         } else {
             for (int c = threadIdx.x; c < h; c += 256) {
                 const float f = FUSED ? rowbuf[c] : ld_elem<F16>(xr + c);
-                orow[c] = to_bits<F16>(round_io<F16>(f * inv) * ld_elem<F16>(w + c));
+                const unsigned short bits = to_bits<F16>(round_io<F16>(f * inv) * ld_elem<F16>(w + c));
+                orow[c] = bits;
+                if (out2) out2[row * out2_stride + c] = bits;
             }
         }
     }
@@ -195,6 +201,19 @@ extern "C" int sglk_rmsnorm(void* out, int64_t out_stride, const void* x, int64_
     SGLK_CHECK_LAUNCH("rmsnorm");
     return SGLK_OK;
 }
+
+// rmsnorm of bf16 rows written to two places (qkv_proj_with_rope: v_input and the head of k_input are the same rows)
+namespace sglk {
+int launch_rmsnorm_bf16_dual(void* out, int64_t out_stride, void* out2, int64_t out2_stride, const void* x, int64_t x_stride,
+                             const void* weight, int64_t rows, int hidden, float eps, hipStream_t stream) {
+    if (rows == 0) return SGLK_OK;
+    hipLaunchKernelGGL((rmsnorm_kernel<false, false>), dim3((unsigned)row_grid(rows)), dim3(256), 0, stream, (unsigned short*)out,
+                       out_stride, (const unsigned short*)x, x_stride, (unsigned short*)nullptr, (int64_t)0,
+                       (const unsigned short*)weight, rows, hidden, eps, (unsigned short*)out2, out2_stride);
+    SGLK_CHECK_LAUNCH("rmsnorm(dual)");
+    return SGLK_OK;
+}
+}  // namespace sglk
 
 extern "C" int sglk_fused_add_rmsnorm(void* x, int64_t x_stride, void* residual, int64_t res_stride, const void* weight,
                                       int64_t rows, int32_t hidden, float eps, int32_t is_f16, void* stream) {

@@ -247,6 +247,9 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
 // DOWN with two neighbouring column tiles per workgroup (p.n_tiles = output columns / 256; reduction % 256 == 0)
 int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 
+int launch_rmsnorm_bf16_dual(void* out, int64_t out_stride, void* out2, int64_t out2_stride, const void* x, int64_t x_stride,
+                             const void* weight, int64_t rows, int hidden, float eps, hipStream_t stream);
+
 // native MX-fp4 GEMM (gemm_mxfp4.hip): fp4 weights as stored on the block-scaled matrix cores, activations as two e4m3 terms
 size_t mxfp4_native_workspace_bytes(int M, int N, int K);
 bool mxfp4_native_ok(int M, int N, int K, const void* x, int64_t x_stride, const void* wq, const void* out, int64_t out_stride);

@@ -72,6 +72,26 @@ class ScaledMmArgs(ctypes.Structure):
     ]
 
 
+class QkvProjArgs(ctypes.Structure):
+    """Mirror of `sglk_qkv_proj_args`."""
+    _fields_ = [
+        ("hidden", ctypes.c_void_p), ("hidden_stride", ctypes.c_int64), ("B", ctypes.c_int32), ("hidden_size", ctypes.c_int32),
+        ("q_a_w", ctypes.c_void_p), ("q_b_w", ctypes.c_void_p), ("kv_a_w", ctypes.c_void_p),
+        ("q_a_scale", ctypes.c_void_p), ("q_b_scale", ctypes.c_void_p), ("kv_a_scale", ctypes.c_void_p),
+        ("wtype", ctypes.c_int32), ("packed_q_a", ctypes.c_int32), ("packed_q_b", ctypes.c_int32), ("packed_kv_a", ctypes.c_int32),
+        ("block_n", ctypes.c_int32), ("block_k", ctypes.c_int32),
+        ("w_kc", ctypes.c_void_p), ("w_kc_packed", ctypes.c_int32),
+        ("q_a_ln", ctypes.c_void_p), ("kv_a_ln", ctypes.c_void_p), ("eps", ctypes.c_float),
+        ("positions", ctypes.c_void_p), ("positions_is64", ctypes.c_int32),
+        ("cos_sin_cache", ctypes.c_void_p), ("cache_stride", ctypes.c_int64),
+        ("H", ctypes.c_int32), ("q_lora", ctypes.c_int32), ("kv_lora", ctypes.c_int32), ("nope", ctypes.c_int32), ("rope", ctypes.c_int32),
+        ("q_input", ctypes.c_void_p), ("q_stride_b", ctypes.c_int64), ("q_stride_h", ctypes.c_int64),
+        ("k_input", ctypes.c_void_p), ("k_stride_b", ctypes.c_int64),
+        ("v_input", ctypes.c_void_p), ("v_stride_b", ctypes.c_int64),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+    ]
+
+
 class ExtendAttentionArgs(ctypes.Structure):
     """Mirror of `sglk_extend_attention_args`."""
     _fields_ = [
@@ -162,6 +182,8 @@ _SIGNATURES = {
     "sglk_allreduce_sum_bf16": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "sglk_qkv_proj_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 8),
+    "sglk_qkv_proj_with_rope": (ctypes.c_int, [ctypes.POINTER(QkvProjArgs), ctypes.c_void_p]),
     "sglk_mxfp4_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "sglk_ep_plan": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -613,50 +613,53 @@ def qkv_proj_with_rope(hidden_states, q_a_proj_weight, q_b_proj_weight, kv_a_pro
     if cos_sin_cache.dtype != torch.bfloat16 or positions.dtype not in (torch.int64, torch.int32):
         raise RuntimeError("qkv_proj_with_rope: cos_sin_cache must be bfloat16 and positions int64/int32")
     L = _lib.lib()
-    st = _stream(hs)
-
-    if use_int8_w8a8:
+    QL, hidden = q_a_proj_weight.shape
+    if hs.shape[1] != hidden or q_b_proj_weight.shape[1] != QL or kv_a_proj_weight.shape[1] != hidden or \
+            q_a_layernorm_weight.numel() != QL or kv_a_layernorm_weight.numel() != R:
+        raise RuntimeError("qkv_proj_with_rope: weight shapes do not agree")
+    wdt = q_a_proj_weight.dtype
+    if q_b_proj_weight.dtype != wdt or kv_a_proj_weight.dtype != wdt or wdt not in _WTYPE:
+        raise RuntimeError("qkv_proj_with_rope: the three projection weights must share one supported dtype")
+    if use_int8_w8a8 != (wdt == torch.int8) or use_fp8_w8a16 != (wdt == torch.float8_e4m3fn):
+        raise RuntimeError("qkv_proj_with_rope: use_int8_w8a8 / use_fp8_w8a16 do not match the weight dtype")
+    scales = [None, None, None]
+    if use_int8_w8a8 or use_fp8_w8a16:
         if q_a_proj_scale is None or q_b_proj_scale is None or kv_a_proj_scale is None:
-            raise RuntimeError("qkv_proj_with_rope: int8 needs the three weight scales")
-
-        def lin(x, w, s):    # per-token quantisation with the oracle's 1e-7 floor, then W8A8 GEMM, bf16 out
-            x = x if x.stride(-1) == 1 else x.contiguous()
-            q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
-            xs = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-            _lib.check(L.sglk_per_token_quant_int8_floor(_ptr(x), x.stride(0), _ptr(q), q.stride(0), _ptr(xs), x.shape[0],
-                                                         x.shape[1], 1e-7, st), "qkv_proj_with_rope(quant)")
-            return _scaled_mm(q, w, s.reshape(-1), None, torch.bfloat16, is_vnni, None, x_scale=xs)
-    elif use_fp8_w8a16:
-        if block_size is None or len(block_size) != 2:
-            raise RuntimeError("qkv_proj_with_rope: fp8 needs block_size [block_n, block_k]")
-
-        def lin(x, w, s):
-            return _scaled_mm(x, w, s, None, torch.bfloat16, is_vnni, block_size)
-    else:
-        def lin(x, w, s):
-            return _scaled_mm(x, w, None, None, torch.bfloat16, is_vnni, None)
-
-    q = lin(hs, q_a_proj_weight, q_a_proj_scale)
-    qn = torch.empty_like(q)
-    rmsnorm_cpu(qn, q, q_a_layernorm_weight, eps)
-    q = lin(qn, q_b_proj_weight, q_b_proj_scale).view(B, H, qk_head)
-    latent = lin(hs, kv_a_proj_weight, kv_a_proj_scale)                       # [B, R + rope]
-
+            raise RuntimeError("qkv_proj_with_rope: quantised weights need the three weight scales")
+        scales = [t.to(torch.float32).contiguous() for t in (q_a_proj_scale, q_b_proj_scale, kv_a_proj_scale)]
+    if use_fp8_w8a16 and (block_size is None or len(block_size) != 2):
+        raise RuntimeError("qkv_proj_with_rope: fp8 needs block_size [block_n, block_k]")
+    hs = hs if hs.stride(1) == 1 else hs.contiguous()
+    ws_ = [t.contiguous() for t in (q_a_proj_weight, q_b_proj_weight, kv_a_proj_weight)]
+    wk = w_kc if w_kc.is_contiguous() else w_kc.contiguous()
+    ln1, ln2 = q_a_layernorm_weight.contiguous(), kv_a_layernorm_weight.contiguous()
+    if ln1.dtype != torch.bfloat16 or ln2.dtype != torch.bfloat16:
+        raise RuntimeError("qkv_proj_with_rope: layernorm weights must be bfloat16")
+    pos = positions if positions.is_contiguous() else positions.contiguous()
+    cache = cos_sin_cache if cos_sin_cache.stride(-1) == 1 else cos_sin_cache.contiguous()
     q_input = torch.empty(B, H, R + rope_dim, dtype=torch.bfloat16, device=hs.device)
     k_input = torch.empty(B, 1, R + rope_dim, dtype=torch.bfloat16, device=hs.device)
     v_input = torch.empty(B, 1, R, dtype=torch.bfloat16, device=hs.device)
-    wk = w_kc if w_kc.is_contiguous() else w_kc.contiguous()
-    _lib.check(L.sglk_bmm_heads(_ptr(q), q.stride(0), q.stride(1), _ptr(wk), 1 if is_vnni else 0, _ptr(q_input),
-                                q_input.stride(0), q_input.stride(1), B, H, R, nope, st), "qkv_proj_with_rope(w_kc)")
-    rmsnorm_cpu(v_input.view(B, R), latent[:, :R], kv_a_layernorm_weight, eps)
-    k_input[:, 0, :R].copy_(v_input.view(B, R))
-    pos = positions if positions.is_contiguous() else positions.contiguous()
-    cache = cos_sin_cache if cos_sin_cache.stride(-1) == 1 else cos_sin_cache.contiguous()
-    q_pe, k_pe = q[:, :, nope:], latent[:, R:]
-    qo, ko = q_input[:, :, R:], k_input[:, 0, R:]
-    _lib.check(L.sglk_rope_gptj(_ptr(q_pe), q_pe.stride(0), q_pe.stride(1), _ptr(k_pe), k_pe.stride(0), _ptr(pos),
-                                1 if pos.dtype == torch.int64 else 0, _ptr(cache), cache.stride(0), _ptr(qo), qo.stride(0),
-                                qo.stride(1), _ptr(ko), ko.stride(0), B, H, rope_dim, st), "qkv_proj_with_rope(rope)")
+    wtype = _WTYPE[wdt]
+    nbytes = L.sglk_qkv_proj_workspace_bytes(B, hidden, H, QL, R, nope, rope_dim, wtype)
+    ws = _workspace(nbytes, hs.device)
+
+    def packed(w):
+        return 1 if (is_vnni and _pack_supported(w.shape[0], w.shape[1], wdt)) else 0
+
+    args = _lib.QkvProjArgs(
+        hidden=_ptr(hs), hidden_stride=hs.stride(0), B=B, hidden_size=hidden, q_a_w=_ptr(ws_[0]), q_b_w=_ptr(ws_[1]),
+        kv_a_w=_ptr(ws_[2]), q_a_scale=_ptr(scales[0]) if scales[0] is not None else None,
+        q_b_scale=_ptr(scales[1]) if scales[1] is not None else None,
+        kv_a_scale=_ptr(scales[2]) if scales[2] is not None else None, wtype=wtype, packed_q_a=packed(ws_[0]),
+        packed_q_b=packed(ws_[1]), packed_kv_a=packed(ws_[2]), block_n=int(block_size[0]) if use_fp8_w8a16 else 0,
+        block_k=int(block_size[1]) if use_fp8_w8a16 else 0, w_kc=_ptr(wk), w_kc_packed=1 if is_vnni else 0, q_a_ln=_ptr(ln1),
+        kv_a_ln=_ptr(ln2), eps=float(eps), positions=_ptr(pos), positions_is64=1 if pos.dtype == torch.int64 else 0,
+        cos_sin_cache=_ptr(cache), cache_stride=cache.stride(0), H=H, q_lora=QL, kv_lora=R, nope=nope, rope=rope_dim,
+        q_input=_ptr(q_input), q_stride_b=q_input.stride(0), q_stride_h=q_input.stride(1), k_input=_ptr(k_input),
+        k_stride_b=k_input.stride(0), v_input=_ptr(v_input), v_stride_b=v_input.stride(0), workspace=_ptr(ws),
+        workspace_bytes=nbytes)
+    _lib.check(L.sglk_qkv_proj_with_rope(ctypes.byref(args), _stream(hs)), "qkv_proj_with_rope")
     return q_input, k_input, v_input
 
 
