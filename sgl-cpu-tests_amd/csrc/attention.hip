@@ -531,12 +531,14 @@ SGLK_DEV int vswz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
 template <int WIDTH, int FORM, bool VIMG = false>
 struct HalfDma {
     static constexpr int CH = WIDTH / 8;
-    const unsigned short* g[2];
+    static constexpr int N = CH / 8;                 // instructions per thread: a group's 32 rows x CH chunks over 256 threads
+    static_assert(CH % 8 == 0, "row width must be a multiple of 64 elements");
+    const unsigned short* g[N];
     SGLK_DEV void prep(const KvSource& src, int p0, int nkeys, int grp, int t256) {
         constexpr int MASK = Swz<CH>::mask;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = grp * 512 + i * 256 + t256;
+        for (int i = 0; i < N; ++i) {
+            const int c = grp * (32 * CH) + i * 256 + t256;
             const int row = c / CH, slot = c - row * CH;
             const int rr = row < nkeys ? row : nkeys - 1;
             const int pos = p0 + rr;
@@ -557,8 +559,8 @@ struct HalfDma {
     }
     SGLK_DEV void issue(unsigned char* lds, int grp, int wv) const {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((dma_gptr_t)g[i], (dma_lptr_t)(lds + (grp * 512 + i * 256 + wv * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < N; ++i)
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)g[i], (dma_lptr_t)(lds + (grp * (32 * CH) + i * 256 + wv * 64) * 16), 16, 0, 0);
     }
 };
 
@@ -574,12 +576,16 @@ SGLK_DEV float xor32_max(float v) {
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
-struct CorePP {
-    static constexpr int D = 128, DV = 128, QT = 2, KS = 4, VT = 8, NKT = 4;
 #ifndef SGLK_PP_AHEAD
 #define SGLK_PP_AHEAD 4
 #endif
-    static constexpr int kAhead = SGLK_PP_AHEAD;   // operand fragments (16 bytes per lane) in flight ahead of the MFMAs
+#ifndef SGLK_PP_AHEAD_192
+#define SGLK_PP_AHEAD_192 2
+#endif
+template <int D_, int AHEAD = SGLK_PP_AHEAD>
+struct CorePP {
+    static constexpr int D = D_, DV = 128, QT = 2, KS = D_ / 32, VT = 8, NKT = 4;
+    static constexpr int kAhead = AHEAD;   // operand fragments (16 bytes per lane) in flight ahead of the MFMAs
     bf16x8 qf[QT][KS];
     f32x4 o[QT][VT];
     f32x4 s[QT][NKT];
@@ -640,7 +646,7 @@ struct CorePP {
         }
         __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
-        for (int i = 0; i < 16 - kAhead; ++i) {
+        for (int i = 0; i < KS * NKT - kAhead; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -811,10 +817,11 @@ SGLK_DEV void slot_barrier_v() {             // ... and this wave's LDS-DMA halv
 #ifndef SGLK_PP_PRIO
 #define SGLK_PP_PRIO 2
 #endif
-template <int FORM>   // 0 = extend_attention_cpu, 1 = flash_attn_varlen_func (exact head dims, aligned rows)
+// D = 128 or 192 (the MLA prefill head of /root/reference/bench_extend.py:111-112), DV = 128
+template <int FORM, int D = 128>   // FORM 0 = extend_attention_cpu, 1 = flash_attn_varlen_func (exact head dims, aligned rows)
 __global__ __launch_bounds__(512, 2) void extend_pp_kernel(const ExtendParams p) {
     constexpr bool VARLEN = FORM != 0;
-    constexpr int D = 128, DV = 128, QT = 2, QB = 256, WQ = 32;
+    constexpr int DV = 128, QT = 2, QB = 256, WQ = 32;
     constexpr int KB = kKeys * D * 2, VB = kKeys * DV * 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char pp_lds[];   // K ring [3][KB], V ring [3][VB]
     unsigned char* const kring = pp_lds;
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void extend_pp_kernel(const ExtendParams p)
     const int grp = wave >> 2;                    // 0: group A, 1: group B (one slot behind)
     // the two waves of a SIMD take neighbouring 32-query slices, so that they see about the same number of tiles
     const int qslot = ((wave & 3) << 1) | grp;
-    CorePP core;
+    CorePP<D, D == 128 ? SGLK_PP_AHEAD : SGLK_PP_AHEAD_192> core;
     core.init();
     int limit[QT];
 #pragma unroll
@@ -1256,14 +1263,20 @@ extern "C" int sglk_extend_attention(const sglk_extend_attention_args* a, void* 
         SGLK_CHECK_LAUNCH("extend_attention");                                                         \
         return SGLK_OK;                                                                                \
     }
-    if (a->D == 128 && a->DV == 128 && knobs().attn_pp != 0 && knobs().attn_nw != 4) {   // two-phase form (SGLK_ATTN_PP=0: the form above)
+    if ((a->D == 128 || a->D == 192) && a->DV == 128 && knobs().attn_pp != 0 && knobs().attn_nw != 4) {   // two-phase form (SGLK_ATTN_PP=0: the form above)
         p.nqblk = (int)ceil_div(a->max_len_extend, 256);
         p.pair = 0;
         const int64_t wgs = (int64_t)p.nqblk * a->B * a->HQ;
         SGLK_REQUIRE(wgs < (1ll << 31), SGLK_ERR_SHAPE, "extend_attention: too many workgroups");
-        constexpr int kPpLds = 6 * kKeys * 128 * 2;
-        SGLK_ENSURE_DYN_LDS(extend_pp_kernel<0>, kPpLds, "extend_attention");
-        hipLaunchKernelGGL(extend_pp_kernel<0>, dim3((unsigned)wgs), dim3(512), kPpLds, s, p);
+        if (a->D == 128) {
+            constexpr int kPpLds = 3 * kKeys * (128 + 128) * 2;
+            SGLK_ENSURE_DYN_LDS((extend_pp_kernel<0, 128>), kPpLds, "extend_attention");
+            hipLaunchKernelGGL((extend_pp_kernel<0, 128>), dim3((unsigned)wgs), dim3(512), kPpLds, s, p);
+        } else {
+            constexpr int kPpLds = 3 * kKeys * (192 + 128) * 2;
+            SGLK_ENSURE_DYN_LDS((extend_pp_kernel<0, 192>), kPpLds, "extend_attention");
+            hipLaunchKernelGGL((extend_pp_kernel<0, 192>), dim3((unsigned)wgs), dim3(512), kPpLds, s, p);
+        }
         SGLK_CHECK_LAUNCH("extend_attention");
         return SGLK_OK;
     }
