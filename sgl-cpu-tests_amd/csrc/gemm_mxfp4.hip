@@ -91,40 +91,44 @@ struct Fp4Params {
     int M, N, K;
 };
 
+template <int RT>
 struct StepRegs {          // the operands of one 64-deep k-step of a wave
-    uint4 a[4];            // the lane's MX block of each of the four row tiles
+    uint4 a[RT];           // the lane's MX block of each of the wave's row tiles
     uint4 bh[2], bl[2];    // activation chunks, hi and lo term
 };
 
+// RT = 32-row tiles per wave (the workgroup's weight rows): 4 -> 192 registers, two waves per SIMD; 2 -> four waves per SIMD, more
+// loads in flight per SIMD for half the reuse of an activation fragment
+template <int RT>
 __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 128;
+    const int n0 = blockIdx.x * (RT * 32);
     const int tok = blockIdx.y * 128 + wave * 32 + r;
     const int tokc = tok < p.M ? tok : p.M - 1;             // rows past M re-read the last one, never stored
     const int K = p.K, KB = K >> 5;
     const uint8_t* xhi = p.xq + (int64_t)tokc * p.xq_stride + 16 * h;
     const uint8_t* xlo = xhi + K;
     const uint8_t* xsr = p.xs + (int64_t)tokc * p.xs_stride;
-    const uint8_t* wrow[4];
-    const uint8_t* srow[4];                                  // this lane's scale of 32-block kb sits at srow[rt][kb * sstep]
+    const uint8_t* wrow[RT];
+    const uint8_t* srow[RT];                                 // this lane's scale of 32-block kb sits at srow[rt][kb * sstep]
     const int sstep = p.scale_packed ? 32 : 1;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         const int n = n0 + rt * 32 + r;
         wrow[rt] = p.wq + (int64_t)n * (K >> 1) + 16 * h;
         srow[rt] = p.scale_packed ? p.ws + ((int64_t)(n >> 5) * KB) * 32 + (n & 31) : p.ws + (int64_t)n * KB;
     }
-    f32x16 acc[4];
+    f32x16 acc[RT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
 
-    auto load_step = [&](int t, StepRegs& g) __attribute__((always_inline)) {
+    auto load_step = [&](int t, StepRegs<RT>& g) __attribute__((always_inline)) {
         const int kb = t * 32;                               // byte offset of the step inside a weight row
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) g.a[rt] = *reinterpret_cast<const uint4*>(wrow[rt] + kb);
+        for (int rt = 0; rt < RT; ++rt) g.a[rt] = *reinterpret_cast<const uint4*>(wrow[rt] + kb);
         const int k0 = t * 64;
         g.bh[0] = *reinterpret_cast<const uint4*>(xhi + k0);
         g.bh[1] = *reinterpret_cast<const uint4*>(xhi + k0 + 32);
@@ -133,9 +137,9 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
     };
     // scales of the four k-steps of a 256-wide group: byte s of sa[rt] = MX block 8 q + 2 s + h of the lane's row;
     // byte s of sxh = the activation block scale of k-step s (one per 128), sxl = the lo term's (4 binades below)
-    auto load_scales = [&](int q, unsigned (&sa)[4], unsigned& sxh, unsigned& sxl) __attribute__((always_inline)) {
+    auto load_scales = [&](int q, unsigned (&sa)[RT], unsigned& sxh, unsigned& sxl) __attribute__((always_inline)) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
             const uint8_t* sp = srow[rt] + (int64_t)(8 * q + h) * sstep;
             sa[rt] = (unsigned)sp[0] | ((unsigned)sp[2 * sstep] << 8) | ((unsigned)sp[4 * sstep] << 16) | ((unsigned)sp[6 * sstep] << 24);
         }
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
                           (int)G.bh[1].x, (int)G.bh[1].y, (int)G.bh[1].z, (int)G.bh[1].w};                                   \
         const i32x8 bl = {(int)G.bl[0].x, (int)G.bl[0].y, (int)G.bl[0].z, (int)G.bl[0].w,                                    \
                           (int)G.bl[1].x, (int)G.bl[1].y, (int)G.bl[1].z, (int)G.bl[1].w};                                   \
-        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                   \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) {                                                                   \
             const i32x8 a = {(int)G.a[rt].x, (int)G.a[rt].y, (int)G.a[rt].z, (int)G.a[rt].w, 0, 0, 0, 0};                    \
             acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bh, acc[rt], 4, 0, S, (int)sa[rt], S, (int)sxh);    \
             acc[rt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bl, acc[rt], 4, 0, S, (int)sa[rt], S, (int)sxl);    \
@@ -160,8 +164,8 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
     // registers, 422 vs 460 TF at 1024 x 12288 x 2048).  The kernel is bound by L2 round trips, not by the matrix pipe; the next
     // step is staging the activation tile through LDS by DMA, as the MoE kernels do.
     const int nq = K >> 8;
-    StepRegs g0, g1;
-    unsigned sa[4], sxh, sxl;
+    StepRegs<RT> g0, g1;
+    unsigned sa[RT], sxh, sxl;
     load_scales(0, sa, sxh, sxl);
     load_step(0, g0);
     for (int q = 0; q < nq; ++q) {
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
         SGLK_FP4_STEP(1, g1)
         load_step(t + 3, g1);
         SGLK_FP4_STEP(2, g0)
-        unsigned na[4], nxh = 0, nxl = 0;
+        unsigned na[RT], nxh = 0, nxl = 0;
         const bool more = q + 1 < nq;
         if (more) {
             load_step(t + 4, g0);
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
         SGLK_FP4_STEP(3, g1)
         if (more) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) sa[rt] = na[rt];
+            for (int rt = 0; rt < RT; ++rt) sa[rt] = na[rt];
             sxh = nxh;
             sxl = nxl;
         }
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void gemm_mxfp4_kernel(const Fp4Params p) {
     if (tok >= p.M) return;
     uint16_t* orow = p.out + (int64_t)tok * p.out_stride;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n0 + rt * 32 + 8 * g + 4 * h;
@@ -233,7 +237,10 @@ int launch_gemm_mxfp4_native(const void* x, int64_t x_stride, const void* wq, co
     p.xq = xq; p.xq_stride = (int64_t)2 * K; p.xs = xs; p.xs_stride = K >> 7;
     p.wq = (const uint8_t*)wq; p.ws = (const uint8_t*)scales; p.scale_packed = scale_packed; p.bias = bias;
     p.out = (uint16_t*)out; p.out_stride = out_stride; p.M = M; p.N = N; p.K = K;
-    hipLaunchKernelGGL(gemm_mxfp4_kernel, dim3((unsigned)(N / 128), (unsigned)ceil_div(M, 128)), dim3(256), 0, stream, p);
+    if (knobs().mxfp4_rt == 2)
+        hipLaunchKernelGGL(gemm_mxfp4_kernel<2>, dim3((unsigned)(N / 64), (unsigned)ceil_div(M, 128)), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(gemm_mxfp4_kernel<4>, dim3((unsigned)(N / 128), (unsigned)ceil_div(M, 128)), dim3(256), 0, stream, p);
     SGLK_CHECK_LAUNCH("mxfp4_scaled_mm(native)");
     return SGLK_OK;
 }
