@@ -264,6 +264,10 @@ typedef struct {
 } sglk_scaled_mm_args;
 
 size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8);
+/* ... plus room for a re-tiled copy of a ROW-MAJOR weight (packed == 0) when M >= 192 and the shape can be packed: the call
+ * then packs into the workspace and runs the tuned kernels (3-4x the generic engine at prefill sizes).  With only the bytes of
+ * the function above a row-major weight runs on the generic engine at every M. */
+size_t sglk_scaled_mm_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8, int32_t packed);
 int sglk_scaled_mm(const sglk_scaled_mm_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -400,6 +400,25 @@ extern "C" size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K
     return plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8).total;
 }
 
+namespace sglk {
+// Row-major weights at prefill sizes: re-tiling the weight into the workspace (one pass over its bytes) and running the tuned
+// kernel beats the generic engine 3-4x (1000 x 18432 x 2560 int8: 0.32 -> 0.09 ms); decode sizes are bound by the weight bytes
+// and read them once either way.  Shapes sglk_pack_weight takes: bf16 rows % 32 / cols % 8, fp8 / int8 rows % 16 / cols % 64.
+static bool pack_on_the_fly(int M, int N, int K, int wtype, int packed) {
+    if (packed || M < 192 || knobs().force_generic || knobs().no_pack_on_the_fly) return false;
+    if (wtype == SGLK_W_BF16) return N % 32 == 0 && K % 8 == 0;
+    return (wtype == SGLK_W_FP8_E4M3 || wtype == SGLK_W_INT8) && N % 16 == 0 && K % 64 == 0;
+}
+static size_t weight_bytes(int N, int K, int wtype) { return (size_t)N * K * (wtype == SGLK_W_BF16 ? 2 : 1); }
+}  // namespace sglk
+
+extern "C" size_t sglk_scaled_mm_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8,
+                                                    int32_t packed) {
+    if (M < 0 || N <= 0 || K <= 0) return 0;
+    const size_t base = align_up(plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8).total, 256);
+    return pack_on_the_fly(M, N, K, wtype, packed) ? base + align_up(weight_bytes(N, K, wtype), 256) : base;
+}
+
 extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     SGLK_REQUIRE(a, SGLK_ERR_INVALID, "scaled_mm: null args");
     const int M = a->M, N = a->N, K = a->K;
@@ -421,6 +440,19 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     if (M == 0) return SGLK_OK;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)a->workspace;
+    // row-major weight, prefill-size M, and the caller sized the workspace with _ex: re-tile into the workspace, run as packed
+    if (pack_on_the_fly(M, N, K, a->wtype, a->packed)) {
+        const size_t base = align_up(w.total, 256);
+        if (a->workspace_bytes >= base + weight_bytes(N, K, a->wtype)) {
+            rc = sglk_pack_weight(a->w, ws + base, 1, N, K, a->wtype, stream);
+            if (rc != SGLK_OK) return rc;
+            sglk_scaled_mm_args b = *a;
+            b.w = ws + base;
+            b.packed = 1;
+            b.workspace_bytes = base;
+            return sglk_scaled_mm(&b, stream);
+        }
+    }
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
     if (a->out_type == SGLK_OUT_BF16 && !a->x_is_int8 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 &&

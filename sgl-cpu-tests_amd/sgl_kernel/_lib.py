@@ -182,6 +182,7 @@ _SIGNATURES = {
     "sglk_allreduce_sum_bf16": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    "sglk_scaled_mm_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int32] * 6),
     "sglk_qkv_proj_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 8),
     "sglk_qkv_proj_with_rope": (ctypes.c_int, [ctypes.POINTER(QkvProjArgs), ctypes.c_void_p]),
     "sglk_mxfp4_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),

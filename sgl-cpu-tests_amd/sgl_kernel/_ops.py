@@ -528,7 +528,8 @@ def _scaled_mm(x, w, w_scale, bias, out_dtype, is_vnni, block, x_scale=None):
     out = torch.empty(M, N, dtype=out_dtype, device=x.device)
     L = _lib.lib()
     wtype = _WTYPE[w.dtype]
-    ws_bytes = L.sglk_scaled_mm_workspace_bytes(M, N, K, wtype, int(x_is_int8))
+    packed = 1 if (is_vnni and _pack_supported(N, K, w.dtype)) else 0
+    ws_bytes = L.sglk_scaled_mm_workspace_bytes_ex(M, N, K, wtype, int(x_is_int8), packed)
     ws = _workspace(ws_bytes, x.device)
     args = _lib.ScaledMmArgs(
         x=x.data_ptr(), x_stride=x.stride(0), x_is_int8=int(x_is_int8),
@@ -536,7 +537,7 @@ def _scaled_mm(x, w, w_scale, bias, out_dtype, is_vnni, block, x_scale=None):
         w_scale=w_scale.data_ptr() if w_scale is not None else None,
         bias=bias.data_ptr() if bias is not None else None, out=out.data_ptr(), out_stride=out.stride(0),
         out_type=_OUT_TYPE[out_dtype], M=M, N=N, K=K, wtype=wtype,
-        packed=1 if (is_vnni and _pack_supported(N, K, w.dtype)) else 0,
+        packed=packed,
         block_n=int(block[0]) if block else 0, block_k=int(block[1]) if block else 0,
         workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
     _lib.check(L.sglk_scaled_mm(ctypes.byref(args), _stream(x)), "scaled_mm")
