@@ -156,7 +156,18 @@ def main():
         from sgl_kernel.expert_parallel import ExpertParallelMoE
         # SGLK_EP_CAPACITY=c (0 < c <= 1): fixed segments of ceil(c * tokens) rows per destination, no host read of the counts
         cap_env = os.environ.get("SGLK_EP_CAPACITY")
-        ep = ExpertParallelMoE(N_EXPERTS, local_experts, capacity_factor=float(cap_env) if cap_env else None, profile=True)
+        cap = float(cap_env) if cap_env else None
+        if cap is None and not os.environ.get("SGLK_EP_EXACT"):
+            # default: fixed segments sized from the routing itself (what a deployment takes from a routing profile): the most
+            # rows any rank sends to any destination, over all ranks, rounded up to 64 -- no host read of the counts per step and
+            # no dropped token by construction (the overflow flag is still checked after the run).  SGLK_EP_EXACT=1: exact counts.
+            dest = torch.div(ids, N_EXPERTS // world, rounding_mode="floor")
+            rows = torch.stack([(dest == d).any(dim=1).sum() for d in range(world)]).max().to(torch.int64)
+            if backend == "gloo":
+                rows = rows.cpu()
+            dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            cap = min(1.0, ((int(rows.item()) + 63) // 64 * 64) / M)
+        ep = ExpertParallelMoE(N_EXPERTS, local_experts, capacity_factor=cap, profile=True)
 
         def step():
             out = ep(inputs[step_idx[0] % n_inputs], tw, ids)
@@ -360,8 +371,12 @@ def main():
         if world > 1:
             # rank 0's view of the exchange: mean ms per phase over the timed steps (HIP events on each step's stream) and the
             # bytes one step moves out of / back into this GPU
-            line["ep"] = {"phase_ms": ep.phase_ms(), "split_mode": "fixed capacity, no host read" if ep.capacity_factor else
-                          "exact counts, one host read per step", **ep.last_stats}
+            ovf = int(ep.last_overflow.item()) if (ep.capacity_factor and ep.last_overflow is not None) else 0
+            line["ep"] = {"phase_ms": ep.phase_ms(), "split_mode": f"fixed capacity {ep.capacity_factor:.4f} of the tokens per "
+                          "destination (sized from the routing at setup), no host read" if ep.capacity_factor else
+                          "exact counts, one host read per step", "overflow_mask": ovf, **ep.last_stats}
+            if ovf:
+                line["verified"] = False       # a segment overflowed: tokens were dropped, the number is not valid
         if world == 1 and args.a8:
             try:
                 line["a8"] = bench_a8()
