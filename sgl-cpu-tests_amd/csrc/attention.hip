@@ -160,9 +160,7 @@ struct Core {
     // DV here is the width of the V slice this wave accumulates; dv0 = its first column inside the V image, whose rows
     // are VROW elements wide (0 = DV, i.e. the wave owns the whole width)
     // NKT = 16-key tiles this wave takes from the image (4 = all 64 keys; 2 = the 32 keys from row k0, decode kernel)
-    // PIPE > 0 (extend kernel): the operand reads of both products are issued PIPE fragments ahead of the MFMAs that consume
-    // them (scheduling fences; left alone the scheduler keeps one or two reads in flight and each MFMA pair waits an LDS round trip)
-    template <bool V_ALIAS, int VROW = 0, int NKT = 4, int PIPE = 0>
+    template <bool V_ALIAS, int VROW = 0, int NKT = 4>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
                        float scale_log2e, float logit_cap, int lane, int dv0 = 0, int k0 = 0) {
         int lim_min = limit[0];
@@ -191,17 +189,6 @@ struct Core {
                 for (int qt = 0; qt < QT; ++qt)
                     s[qt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ks], s[qt][kt], 0, 0, 0);
             }
-        }
-        if constexpr (PIPE > 0) {
-            constexpr int NF = KS * NKT;
-            __builtin_amdgcn_sched_group_barrier(0x100, PIPE, 0);
-#pragma unroll
-            for (int i = 0; i < NF - PIPE; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < PIPE; ++i) __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
         }
         // ---- online softmax per column (lane) ----
         bf16x8 pf[QT][NKT / 2];
@@ -296,17 +283,6 @@ struct Core {
                     o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ss], o[qt][t], 0, 0, 0);
             }
         }
-        if constexpr (PIPE > 0) {
-            constexpr int NF = VT * (NKT / 2);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PIPE, 1);
-#pragma unroll
-            for (int i = 0; i < NF - PIPE; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, QT, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-            }
-#pragma unroll
-            for (int i = 0; i < PIPE; ++i) __builtin_amdgcn_sched_group_barrier(0x008, QT, 1);
-        }
     }
 
     // total of the per-lane partial sums of a column (the 4 lane groups hold disjoint keys)
@@ -361,9 +337,6 @@ static int pair_blocks(int nqblk, int64_t wgs_unpaired, int n_cu, int causal) {
 // rows; 2 = flash_attn_varlen_func with zero-padded head dims and / or rows that are only 4-byte aligned.
 // NW = waves per workgroup: 8 (two per SIMD: one wave's softmax beside the other's MFMAs), or 4 (A/B knob) -- then two
 // workgroups share a CU the same way, each streaming its own K/V tiles, with half the queries per workgroup.
-#ifndef SGLK_EXT_PIPE
-#define SGLK_EXT_PIPE 0
-#endif
 template <int D, int DV, int QT, int FORM, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const ExtendParams p) {
     constexpr bool VARLEN = FORM != 0, RAGGED = FORM == 2;
@@ -467,8 +440,7 @@ __global__ __launch_bounds__(NW * 64, 2) void extend_attention_kernel(const Exte
             kreg.load(ks, (t + 1) * kKeys, nkeys(t + 1), d_real, true);
             vreg.load(vs, (t + 1) * kKeys, nkeys(t + 1), dv_real, v_al);
         }
-        if (t * kKeys < wave_kv_end)
-            core.template tile<false, 0, 4, SGLK_EXT_PIPE>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
+        if (t * kKeys < wave_kv_end) core.template tile<false>(cur, cur + KB, t * kKeys, limit, scale_log2e, p.logit_cap, lane);
         if (more) {
             kreg.store(nxt);      // `nxt` was last read in iteration t-1, which every wave left before this barrier's
             vreg.store(nxt + KB); // predecessor; the barrier below publishes it for iteration t+1
