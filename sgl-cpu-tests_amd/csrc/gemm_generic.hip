@@ -426,9 +426,21 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
     return SGLK_OK;
 }
 
+// A caller that fuses the reduce into its own next kernel (qkv_proj.hip) asks for the split-K partials instead of the reduce
+// launch: while a capture is set on this thread, the reduce is skipped and its description handed over.
+static thread_local SplitkCapture* g_splitk_capture = nullptr;
+void set_splitk_capture(SplitkCapture* c) { g_splitk_capture = c; }
+
 int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream) {
     const int64_t total = (int64_t)p.split_rows * p.n_out;
     if (total == 0) return SGLK_OK;
+    if (g_splitk_capture && !p.bias && !p.addend && !p.moe_ic2 && p.out_type == SGLK_OUT_BF16) {
+        g_splitk_capture->partial = p.partial;
+        g_splitk_capture->ksplit = p.ksplit;
+        g_splitk_capture->rows = p.split_rows;
+        g_splitk_capture->n = p.n_out;
+        return SGLK_OK;
+    }
     int64_t rb = ceil_div(total, 256);
     if (rb > 2048) rb = 2048;
     hipLaunchKernelGGL(gg::splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p, p.split_rows);

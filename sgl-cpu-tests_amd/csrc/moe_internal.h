@@ -224,6 +224,15 @@ int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hi
 // the ordered reduce of split-K partials alone (fields used: partial, ksplit, split_rows, n_out, out, out_type, out_stride,
 // bias, addend*)
 int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream);
+// partial != nullptr after a dense GEMM call: the call left its fp32 split-K partials [ksplit][rows][n] un-reduced (see
+// set_splitk_capture); else the GEMM wrote its bf16 output itself
+struct SplitkCapture {
+    const float* partial;
+    int ksplit;
+    int64_t rows;
+    int n;
+};
+void set_splitk_capture(SplitkCapture* c);   // thread-local; nullptr switches it off
 // ic1 = bf16(silu(gate) * up) from the fp32 split-K partials [range][rows][2n] of a gate_up GEMM
 int launch_splitk_reduce_silu_mul(const float* partial, int ksplit, int rows, int n, uint16_t* out, int64_t out_stride,
                                   hipStream_t stream);
