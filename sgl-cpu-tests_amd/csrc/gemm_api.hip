@@ -625,10 +625,8 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         }
     }
     const int tiles = (int)ceil_div(M, kGenericTileM);
-    rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
-    if (rc != SGLK_OK) return rc;
-
     GenericGemmParams g{};
+    g.dense_rows = M;             // m-tiles derived from M inside the kernel: no table launch
     g.x = a->x;
     g.x_type = a->x_is_int8 ? SGLK_W_INT8 : SGLK_W_BF16;
     g.x_stride = a->x_stride;
@@ -695,9 +693,10 @@ extern "C" int sglk_mxfp4_scaled_mm(const void* x, int64_t x_stride, const void*
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
     const int tiles = (int)ceil_div(M, kGenericTileM);
-    int rc = launch_dense_tiles(M, kGenericTileM, tile_info, num_tiles, nullptr, s);
-    if (rc != SGLK_OK) return rc;
+    int rc = SGLK_OK;
+    (void)rc;
     GenericGemmParams g{};
+    g.dense_rows = M;             // m-tiles derived from M inside the kernel: no table launch
     g.x = x;
     g.x_type = SGLK_W_BF16;
     g.x_stride = x_stride;

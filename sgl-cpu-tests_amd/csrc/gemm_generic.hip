@@ -114,14 +114,21 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GenericGemmPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int live = p.num_tiles[0] * p.n_tiles;
+    const int n_mtiles = p.dense_rows > 0 ? (p.dense_rows + kBM - 1) / kBM : p.num_tiles[0];
+    const int live = n_mtiles * p.n_tiles;
     const bool split = (MODE == GG_PLAIN) && p.ksplit > 1;
     const int ksr = split ? (int)(blockIdx.x % (unsigned)p.ksplit) : 0;            // reduction range of this workgroup
     const int bid = split ? (int)(blockIdx.x / (unsigned)p.ksplit) : (int)blockIdx.x;
     if (bid >= live) return;
     const int mtile = bid / p.n_tiles;
     const int ntile = bid - mtile * p.n_tiles;
-    const int4 ti = p.tile_info[mtile];
+    int4 ti;
+    if (p.dense_rows > 0) {
+        const int left = p.dense_rows - mtile * kBM;
+        ti = make_int4(0, mtile * kBM, left < kBM ? left : kBM, 0);
+    } else {
+        ti = p.tile_info[mtile];
+    }
     const int e = ti.x, pos0 = ti.y, rows = ti.z;
 
     const int C = p.C;

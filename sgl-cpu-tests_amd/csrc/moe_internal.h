@@ -150,6 +150,8 @@ struct GenericGemmParams {
     int gather;
     const int4* tile_info;        // 64-row m-tiles
     const int* num_tiles;
+    int dense_rows;               // > 0: one "expert", m-tile i = rows [64 i, 64 i + 64) of dense_rows -- no tile table is read
+                                  // (saves the table-building launch in front of every decode-size dense GEMM)
     int n_tiles;                  // tiles along output columns
     const void* w;                // [E][R][C]
     int w_type;
