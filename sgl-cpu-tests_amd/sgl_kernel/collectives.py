@@ -82,8 +82,14 @@ class XgmiAllReduce:
             raise RuntimeError("XgmiAllReduce: a peer did not arrive within the spin limit")
 
     def close(self):
+        """Collective: every rank unmaps its peers and frees its own regions.  The barrier keeps a fast rank from freeing memory
+        a slower peer's kernels are still reading."""
         L = self._lib.lib()
         torch.cuda.synchronize()
+        try:
+            dist.barrier(group=self.group)
+        except Exception:           # the group is already gone (interpreter shutdown): nothing left to wait for
+            pass
         for p in self._opened:
             L.sglk_ipc_close(p)
         self._opened = []
