@@ -133,7 +133,12 @@ enum {
      * per token x 128-wide block to e4m3 with a power-of-two scale and both GEMMs run on the block-scaled fp8 matrix
      * cores (v_mfma_scale_f32_32x32x64_f8f6f4).  Needs packed weights, block [128k,128], K % 256 == 0, N % 128 == 0.
      * Stated tolerance: DESIGN.md "a8 mode". */
-    SGLK_MOE_FP8_ACT = 1
+    SGLK_MOE_FP8_ACT = 1,
+    /* the weights are ROW-MAJOR (packed == 0) and the workspace (sized with _workspace_bytes_ex and this flag) has room for a
+     * re-tiled copy: the call packs both weights into the workspace and runs the packed kernels.  One pass over the weight bytes
+     * per call -- worth it from ~64 rows per expert on, where the tuned kernels are 3-4x the generic engine; a caller that
+     * holds its weights packed (the reference's is_vnni=True, bench_moe.py:26-27) never needs it. */
+    SGLK_MOE_PACK_WEIGHTS = 2
 };
 /* path_taken: tile height of the grouped GEMMs (32 / 96 / 128 / 256; 64 = generic engine) | flag bits */
 enum {

@@ -20,7 +20,7 @@ struct StageTimer {
 };
 
 struct Workspace {
-    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tile_info_b, num_tiles_b, tickets, ic1, ic2, xq, xs, ic1q, ic1s, total;
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tile_info_b, num_tiles_b, tickets, ic1, ic2, xq, xs, ic1q, ic1s, wpack, total;
 };
 
 // Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E).  Measured crossovers at Qwen3
@@ -94,6 +94,8 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype, int fl
         w.ic1q = take((size_t)S * N);
         w.ic1s = take((size_t)S * sizeof(float));
     }
+    if (flags & SGLK_MOE_PACK_WEIGHTS)   // re-tiled copies of row-major w1 and w2
+        w.wpack = take((size_t)E * 3 * N * K * (wtype == SGLK_W_BF16 ? 2 : 1));
     w.total = off;
     return w;
 }
@@ -196,6 +198,26 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         SGLK_REQUIRE(N % 16 == 0, SGLK_ERR_SHAPE, "fused_experts(fp8): N (%d) must be a multiple of 16", N);
     } else if (a->wtype == SGLK_W_INT8) {
         SGLK_REQUIRE(a->w1_scale && a->w2_scale, SGLK_ERR_INVALID, "fused_experts: int8 needs w1_scale [E,2N] and w2_scale [E,K]");
+    }
+    if ((a->flags & SGLK_MOE_PACK_WEIGHTS) && a->packed == 0 && M > 0) {
+        const bool ok1 = a->wtype == SGLK_W_BF16 ? ((2 * N) % 32 == 0 && K % 8 == 0) : ((2 * N) % 16 == 0 && K % 64 == 0);
+        const bool ok2 = a->wtype == SGLK_W_BF16 ? (K % 32 == 0 && N % 8 == 0) : (K % 16 == 0 && N % 64 == 0);
+        const Workspace wp = plan_workspace(M, N, K, E, topk, a->wtype, a->flags);
+        if (ok1 && ok2 && a->workspace_bytes >= wp.total) {
+            const size_t elt = a->wtype == SGLK_W_BF16 ? 2 : 1;
+            unsigned char* p1 = (unsigned char*)a->workspace + wp.wpack;
+            unsigned char* p2 = p1 + (size_t)E * 2 * N * K * elt;
+            int rcp = sglk_pack_weight(a->w1, p1, E, 2 * N, K, a->wtype, stream);
+            if (rcp != SGLK_OK) return rcp;
+            rcp = sglk_pack_weight(a->w2, p2, E, K, N, a->wtype, stream);
+            if (rcp != SGLK_OK) return rcp;
+            sglk_fused_experts_args b = *a;
+            b.w1 = p1;
+            b.w2 = p2;
+            b.packed = 3;
+            b.flags &= ~SGLK_MOE_PACK_WEIGHTS;
+            return fused_experts_impl(&b, stream, route, shared);
+        }
     }
     if (a->packed & 1) {
         const bool ok = a->wtype == SGLK_W_BF16 ? ((2 * N) % 32 == 0 && K % 8 == 0) : ((2 * N) % 16 == 0 && K % 64 == 0);

@@ -263,6 +263,9 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
     L = _lib.lib()
     wtype = _WTYPE[wdtype]
     flags = _lib.MOE_FP8_ACT if (_fp8_act and int(method) == FP8_W8A16) else 0
+    pk = _packed_bits(is_vnni, (2 * N, K), (K, N), wdtype)
+    if pk == 0 and M * topk >= 64 * E and _pack_supported(2 * N, K, wdtype) and _pack_supported(K, N, wdtype):
+        flags |= _lib.MOE_PACK_WEIGHTS      # row-major weights at prefill sizes: re-tile into the workspace (one pass over them)
     ws_bytes = L.sglk_fused_experts_workspace_bytes_ex(M, N, K, E, topk, wtype, flags)
     ws = _workspace(ws_bytes, hidden_states.device)
     # second stream for the tail tiles: only the batch sizes that have them (full 256-row tiles plus short tails)

@@ -223,3 +223,19 @@ def test_fused_experts_fp8_mid_odd_and_long_reductions(ops, shape, knob):
     inp["topk_weight"] = inp["topk_weight"] * k
     out, _ = run_fp8(ops, inp, block)
     check_close(out, ref * k, f"mid kernel {shape}")
+
+
+def test_fused_experts_fp8_rowmajor_weights_are_retiled_at_prefill_sizes(ops):
+    """is_vnni=False (the reference's un-prepacked call form, /root/reference/test_moe_fp8_ext.py:118) from 64 rows per expert on:
+    the call re-tiles the weights into its workspace (SGLK_MOE_PACK_WEIGHTS) and runs the packed kernels -- the same bits as a
+    caller that packed them itself; below that size the row-major generic engine answers within the usual tolerance."""
+    N, K, E, topk, bn, bk = 256, 512, 8, 2, 128, 128
+    for M, exact in ((1500, True), (40, False)):
+        inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 6100 + M)
+        packed, d = run_fp8(ops, inp, (bn, bk))
+        rowmajor = ops.fused_experts_cpu(d["a"], d["w1"], d["w2"], d["topk_weight"], d["topk_ids"], False, False, True,
+                                         d["w1s"], d["w2s"], [bn, bk], None, None, False)
+        if exact:
+            assert torch.equal(packed, rowmajor)
+        ref = moe.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+        check_close(rowmajor, ref, f"row-major M={M}")
