@@ -1392,7 +1392,7 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
         constexpr size_t kb = (size_t)kKeys * DD * 2, vb = (AL) ? 0 : (size_t)kKeys * DDV * 2;                     \
         constexpr size_t lds = (2 * (kb + vb) <= SGLK_DEC_DOUBLE_LIMIT) ? 2 * (kb + vb) : (kb + vb);                \
         constexpr int kh = DD >= 256 ? SGLK_DEC_KH_WIDE : 1;   /* wide heads: the tile's keys are split over two wave groups */ \
-        hipFuncSetAttribute((const void*)decode_attention_kernel<DD, DDV, AL, ND, kh>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        SGLK_ENSURE_DYN_LDS((decode_attention_kernel<DD, DDV, AL, ND, kh>), lds, "decode_attention");           \
         hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND, kh>), grid, dim3(256 * kh), lds, s, p);       \
     }
 #define DEC_CASE(DD, DDV)                                                                                          \

@@ -6,7 +6,7 @@
 // One workgroup per row, 16-byte accesses whenever the row is 16-byte aligned and a multiple of 8 wide, scalar
 // fallback otherwise (hidden size 4109 is one of the reference's shapes).  fp32 math, roundings placed where the
 // reference's torch code places them.
-#include "sglk_common.h"
+#include "knobs.h"
 
 namespace sglk {
 
@@ -226,14 +226,12 @@ extern "C" int sglk_fused_add_rmsnorm(void* x, int64_t x_stride, void* residual,
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)hidden * 4;
     if (is_f16) {
-        if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void*)rmsnorm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) SGLK_ENSURE_DYN_LDS((rmsnorm_kernel<true, true>), 150 * 1024, "fused_add_rmsnorm");
         hipLaunchKernelGGL((rmsnorm_kernel<true, true>), grid, block, lds, s, (unsigned short*)x, x_stride,
                            (const unsigned short*)x, x_stride, (unsigned short*)residual, res_stride,
                            (const unsigned short*)weight, rows, hidden, eps);
     } else {
-        if (lds > 48 * 1024)
-            hipFuncSetAttribute((const void*)rmsnorm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 48 * 1024) SGLK_ENSURE_DYN_LDS((rmsnorm_kernel<false, true>), 150 * 1024, "fused_add_rmsnorm");
         hipLaunchKernelGGL((rmsnorm_kernel<false, true>), grid, block, lds, s, (unsigned short*)x, x_stride,
                            (const unsigned short*)x, x_stride, (unsigned short*)residual, res_stride,
                            (const unsigned short*)weight, rows, hidden, eps);
