@@ -10,7 +10,7 @@ namespace sglk {
 
 struct Knobs {
     int moe_tile_m = 0;          // SGLK_MOE_TILE_M: force the fp8 grouped-GEMM tiling (32 / 96 / 128 / 256); 0 = by batch size
-    int mid_lo = 8, mid_hi = 72; // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256
+    int mid_lo = 8, mid_hi = 160; // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
     bool no_i8_mid = false;      // SGLK_NO_I8_MID
     bool no_bf16_mid = false;    // SGLK_NO_BF16_MID

@@ -269,7 +269,7 @@ def _fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace, metho
     ws_bytes = L.sglk_fused_experts_workspace_bytes_ex(M, N, K, E, topk, wtype, flags)
     ws = _workspace(ws_bytes, hidden_states.device)
     # second stream for the tail tiles: only the batch sizes that have them (full 256-row tiles plus short tails)
-    aux = _aux(hidden_states.device) if (int(method) == FP8_W8A16 and 72 * E <= M * topk < 640 * E) else None
+    aux = _aux(hidden_states.device) if (int(method) == FP8_W8A16 and 160 * E <= M * topk < 640 * E) else None
     path = ctypes.c_int32(0)
     args = _lib.FusedExpertsArgs(
         hidden=hidden_states_c.data_ptr(), hidden_stride=hidden_states_c.stride(0),
