@@ -119,13 +119,13 @@ bool tuned_fp8_ok(const sglk_fused_experts_args* a) {
 bool mid_int8_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
-           S < (int64_t)44 * a->E && !knobs().force_generic && !knobs().no_i8_mid;
+           S < (int64_t)knobs().mid_i8_hi * a->E && !knobs().force_generic && !knobs().no_i8_mid;
 }
 
 bool tuned_int8_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_INT8 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 256 &&
-           S >= (int64_t)44 * a->E && (int64_t)a->M * a->K < (1ll << 32) && S * (int64_t)a->N < (1ll << 32) &&
+           S >= (int64_t)knobs().mid_i8_hi * a->E && (int64_t)a->M * a->K < (1ll << 32) && S * (int64_t)a->N < (1ll << 32) &&
            (int64_t)2 * a->N * a->K < (1ll << 32) && !knobs().force_generic;
 }
 
@@ -135,14 +135,14 @@ bool tuned_int8_ok(const sglk_fused_experts_args* a) {
 bool mid_bf16_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 128 == 0 && a->N % 128 == 0 && a->K >= 256 && a->N >= 256 &&
-           S < (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+           S < (int64_t)knobs().mid_bf16_hi * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
            !knobs().force_generic && !knobs().no_bf16_mid;
 }
 
 bool tuned_bf16_ok(const sglk_fused_experts_args* a) {
     const int64_t S = (int64_t)a->M * a->topk;
     return a->wtype == SGLK_W_BF16 && (a->packed & 3) == 3 && a->K % 256 == 0 && a->N % 128 == 0 && a->N >= 128 &&
-           S >= (int64_t)44 * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+           S >= (int64_t)knobs().mid_bf16_hi * a->E && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
            (int64_t)a->M * a->hidden_stride * 2 < (1ll << 32) && S * (int64_t)a->N * 2 < (1ll << 32) &&
            (int64_t)4 * a->N * a->K < (1ll << 32) && !knobs().force_generic;
 }
