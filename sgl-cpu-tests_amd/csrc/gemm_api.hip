@@ -19,6 +19,19 @@ bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int
            (int64_t)M * x_stride * 2 < (1ll << 32) && (int64_t)R * C < (1ll << 32) && !knobs().force_generic;
 }
 
+// Dense GEMM, packed weights: weight-streaming (split-K) kernel or 256-row tile kernel?  Below 192 rows always the former.  From
+// there to SGLK_DENSE_MID_MAX (1024) the 256-row kernel only has ceil(M / 256) x N / 256 workgroups -- 16 for a 4096-wide layer --
+// and loses to the streaming kernels by 2-4x until it can fill a good part of the chip (same-box A/B, tools/ab_dense_mid.py,
+// profiles/r02_ab_dense_mid.txt: 192 x 4096 x 4096 fp8 0.096 -> 0.025 ms, bf16 0.072 -> 0.036; 1000 x 2048 x 6144 fp8 0.118 -> 0.053;
+// a 12288-wide bf16 layer stays on the 256-row kernel).  Without split-K that kernel's time is one tile's time (K / 64 stages)
+// however few tiles there are.
+bool dense_prefers_mid(int M, int N, int wtype) {
+    if (M < 192) return true;
+    if (M >= knobs().dense_mid_max) return false;
+    const int64_t wgs = ceil_div(M, 256) * (int64_t)(N / 256);
+    return wgs <= (wtype == SGLK_W_FP8_E4M3 ? 96 : 32);
+}
+
 void fill_tuned(MoeGemmParams& g, const void* x, int64_t x_stride, int M, const int* ident, const void* w,
                 const float* scale, int R, int C, int block_n, const int4* tile_info, const int* num_tiles) {
     g.x = (const uint16_t*)x;
@@ -457,7 +470,8 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     int* num_tiles = (int*)(ws + w.num_tiles);
     if (a->out_type == SGLK_OUT_BF16 && !a->x_is_int8 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 &&
         (!a->bias || ((uintptr_t)a->bias % 16) == 0) &&
-        tuned_dense_ok(M, N, K, a->wtype, a->packed, a->block_n, a->block_k, a->x, a->x_stride)) {
+        tuned_dense_ok(M, N, K, a->wtype, a->packed, a->block_n, a->block_k, a->x, a->x_stride) &&
+        !(dense_prefers_mid(M, N, a->wtype) && mid_dense_ksplit(M, N, K) >= 1 && a->block_n % 16 == 0)) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
         rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
@@ -506,7 +520,9 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     if (a->wtype == SGLK_W_BF16 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->x_stride % 8 == 0 &&
         ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 && ((uintptr_t)a->out % 8) == 0 &&
         (!a->bias || ((uintptr_t)a->bias % 16) == 0) && ((uintptr_t)a->w % 4) == 0 && !knobs().force_generic) {
-        const int ks = bf16_mid_ksplit(M, N, K);
+        // from 192 rows on only when the 256-row kernel below would have too few workgroups (or cannot take the shape)
+        const bool tuned_can = N % 256 == 0 && K % 32 == 0 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0;
+        const int ks = (M < 192 || !tuned_can || dense_prefers_mid(M, N, a->wtype)) ? bf16_mid_ksplit(M, N, K) : 0;
         if (ks >= 1) {
             BmidParams q{};
             q.x = (const uint16_t*)a->x;
