@@ -180,7 +180,11 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
     uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
-    if ((a->packed & 3) == 3 && N % 128 == 0 &&
+    // (up to SGLK_SHARED_MID_MAX rows the split-K passes below are taken even where the tile kernel could run)
+    const bool shared_mid = M < knobs().shared_mid_max && a->wtype == SGLK_W_FP8_E4M3 && a->block_k == 128 && a->block_n > 0 &&
+                            a->block_n % 16 == 0 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+                            mid_dense_ksplit(M, 2 * N, K) >= 1 && mid_dense_ksplit(M, K, N) >= 1;
+    if ((a->packed & 3) == 3 && N % 128 == 0 && !shared_mid &&
         tuned_dense_ok(M, K, N, a->wtype, 1, a->block_n, a->block_k, ic1, N) &&
         tuned_dense_ok(M, 2 * N, K, a->wtype, 1, a->block_n, a->block_k, a->hidden, a->hidden_stride) &&
         a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && a->fused_out_stride % 4 == 0) {

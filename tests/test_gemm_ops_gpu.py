@@ -157,6 +157,27 @@ def test_shared_expert_fp8(ops, case, prepack):
     assert rel_rms(out, g["ref_out_f32"]) < 6e-3
 
 
+@pytest.mark.parametrize("M", [192, 300, 700, 1000])
+def test_shared_expert_fp8_between_decode_and_prefill_sizes(ops, knob, M):
+    """192 <= M < 1024 runs as split-K passes of the weight-streaming kernel (the 256-row tile kernel has a handful of
+    workgroups there: 0.19 -> 0.06 ms at 192 x 2048 x 7168): same contract (/root/reference/test_moe_fp8_ext.py:52-63) against
+    the fp32 oracle composition, and within rounding of the tile-kernel path (SGLK_SHARED_MID_MAX=192)."""
+    N, K, rsf, bn, bk = 256, 1024, 2.5, 128, 128
+    inp = cuda(recipes.shared_fp8_inputs(M, N, K, 5300 + M, bn, bk))
+    w1, w2 = ops.convert_weight_packed(inp["w1"]), ops.convert_weight_packed(inp["w2"])
+    call = lambda: ops.shared_expert_cpu(inp["a"], w1, w2, inp["fused"], rsf, False, False, True, inp["w1s"], inp["w2s"], [bn, bk],
+                                         None, None, True)
+    out = call()
+    W1 = moe.dequant_block_fp8(inp["w1"].cpu(), inp["w1s"].cpu(), bn, bk)
+    W2 = moe.dequant_block_fp8(inp["w2"].cpu(), inp["w2s"].cpu(), bn, bk)
+    ref = moe.shared_expert_f32(inp["a"].cpu(), W1, W2, inp["fused"].cpu().float(), rsf)
+    assert ref_pred(ref, out)
+    assert rel_rms(out, ref) < 6e-3
+    knob(SGLK_SHARED_MID_MAX=192)
+    tile = call()
+    assert rel_rms(out, tile.float().cpu()) < 4e-3
+
+
 # ---- dense GEMMs -----------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prepack", [False, True])
 @pytest.mark.parametrize("case", recipes.GEMM_BF16_CASES, ids=lambda c: c[0])
