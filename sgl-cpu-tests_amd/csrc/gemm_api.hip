@@ -32,6 +32,24 @@ bool dense_prefers_mid(int M, int N, int wtype) {
     return wgs <= (wtype == SGLK_W_FP8_E4M3 ? 96 : 32);
 }
 
+// Split-K for the 256-row fp8 tile kernel in dense mode: with ceil(M / 256) x N / 256 workgroups well under the CU count the
+// launch takes one tile's time on a part of the chip; K ranges (fp32 partials, ordered reduce) fill it.  Ranges are whole
+// 128-wide blocks, at least sixteen per range, as many ranges as keep the workgroup count within ~1.25 x the CUs.
+int tuned_fp8_ksplit(int M, int N, int K) {
+    if (knobs().no_tuned_splitk || N % 256 != 0 || K % 128 != 0) return 1;
+    const int64_t wgs = ceil_div(M, 256) * (int64_t)(N / 256);
+    const int cus = device_cu_count(), kb = K >> 7;
+    if (wgs * 2 > cus) return 1;
+    int best = 1;
+    for (int ks = 2; ks <= 8; ++ks) {
+        if (kb % ks != 0 || kb / ks < 16) continue;   // shorter ranges lose to the fp32 partial round trip (4096 x 1536 x 2048: 0.051 -> 0.056 ms)
+        if (wgs * ks > cus + cus / 4) break;
+        if ((int64_t)ks * M * N * 4 > (256ll << 20)) break;
+        best = ks;
+    }
+    return best;
+}
+
 void fill_tuned(MoeGemmParams& g, const void* x, int64_t x_stride, int M, const int* ident, const void* w,
                 const float* scale, int R, int C, int block_n, const int4* tile_info, const int* num_tiles) {
     g.x = (const uint16_t*)x;
@@ -92,6 +110,10 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
         if (kb > ks) ks = kb;
         const int ki = i8_mid_ksplit(M, N, K);
         if (ki > ks) ks = ki;
+        if (M >= 192) {                                     // 256-row fp8 tile kernel with K ranges
+            const int kt = tuned_fp8_ksplit(M, N, K);
+            if (kt > ks) ks = kt;
+        }
         if (ks > 1) w.partial = take((size_t)ks * M * N * 4);
     }
     w.total = off;
@@ -478,6 +500,36 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         !(dense_prefers_mid(M, N, a->wtype) && mid_dense_ksplit(M, N, K) >= 1 && a->block_n % 16 == 0)) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
+        const int kt = tuned_fp8_ksplit(M, N, K);
+        if (kt > 1 && w.partial) {   // K ranges as the tile table's "experts", fp32 partials, ordered reduce (+ bias)
+            rc = launch_dense_tiles_ksplit(M, 256, kt, tile_info, num_tiles, ident, s);
+            if (rc != SGLK_OK) return rc;
+            const int kr = K / kt;
+            MoeGemmParams t{};
+            fill_tuned(t, a->x, a->x_stride, M, ident, a->w, a->w_scale, N, K, a->block_n, tile_info, num_tiles);
+            t.C = kr;
+            t.c_full = K;
+            t.w_expert_stride = (int64_t)(kr >> 6) * 1024;
+            t.w_bytes_total = (int64_t)N * K;
+            t.n_tiles = N / 256;
+            t.ksplit = kt;
+            t.split_kblocks = kr >> 7;
+            t.split_rows = M;
+            t.out_cols = N;
+            t.partial = (float*)(ws + w.partial);
+            rc = launch_moe_gemm_fp8w_256i(MODE_PLAIN, t, t256 * kt, s);
+            if (rc != SGLK_OK) return rc;
+            GenericGemmParams r{};
+            r.partial = t.partial;
+            r.ksplit = kt;
+            r.split_rows = M;
+            r.n_out = N;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.bias = a->bias;
+            return launch_splitk_reduce(r, s);
+        }
         rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
         if (rc != SGLK_OK) return rc;
         MoeGemmParams t{};

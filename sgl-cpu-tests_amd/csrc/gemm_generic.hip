@@ -395,6 +395,30 @@ __global__ void dense_tiles_kernel(int M, int tile_m, int4* tile_info, int* num_
     if (blockIdx.x == 0 && threadIdx.x == 0) num_tiles[0] = n;
 }
 
+// ... with ksplit K ranges per m-tile: entry (range, first row, rows), ranges fastest so that the workgroups of one m-tile
+// (which share its activation rows) are neighbours
+__global__ void dense_tiles_ksplit_kernel(int M, int tile_m, int ksplit, int4* tile_info, int* num_tiles, int* identity_slots) {
+    const int n = (M + tile_m - 1) / tile_m;
+    if (identity_slots)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) identity_slots[i] = i;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * ksplit; i += gridDim.x * blockDim.x) {
+        const int mt = i / ksplit, ks = i - mt * ksplit;
+        const int rows = M - mt * tile_m < tile_m ? M - mt * tile_m : tile_m;
+        tile_info[i] = make_int4(ks, mt * tile_m, rows, 0);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) num_tiles[0] = n * ksplit;
+}
+
+int launch_dense_tiles_ksplit(int M, int tile_m, int ksplit, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream) {
+    const int n = identity_slots ? M : ((M + tile_m - 1) / tile_m) * ksplit;
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dense_tiles_ksplit_kernel, dim3(blocks), dim3(256), 0, stream, M, tile_m, ksplit, tile_info, num_tiles, identity_slots);
+    SGLK_CHECK_LAUNCH("dense_tiles");
+    return SGLK_OK;
+}
+
 int launch_dense_tiles(int M, int tile_m, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream) {
     const int n = identity_slots ? M : (M + tile_m - 1) / tile_m;
     int blocks = (n + 255) / 256;

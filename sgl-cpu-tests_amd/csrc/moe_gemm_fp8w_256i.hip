@@ -148,7 +148,8 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         (void)mt;
         const int e_ = __builtin_amdgcn_readfirstlane(m.ti.x), pos0_ = __builtin_amdgcn_readfirstlane(m.ti.y);
         const int rows_ = __builtin_amdgcn_readfirstlane(m.ti.z);
-        const float* scale_e = p.w_scale + (int64_t)e_ * p.scale_rows * p.scale_cols;
+        const bool ksp = MODE == MODE_PLAIN && p.ksplit > 1;      // dense split-K: the "expert" is the K range
+        const float* scale_e = ksp ? p.w_scale + (int64_t)e_ * p.split_kblocks : p.w_scale + (int64_t)e_ * p.scale_rows * p.scale_cols;
         const float inv_bn = 1.0f / (float)p.block_n;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -227,9 +228,11 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     //      tile; the stage offset goes in the scalar soffset, so a stage costs 6 buffer_load...lds and no VALU ----
     const unsigned xbytes = (unsigned)__builtin_amdgcn_readfirstlane((int)p.x_bytes);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xbytes, 0x00020000);
+    const bool ksp = MODE == MODE_PLAIN && p.ksplit > 1;          // dense split-K: tile-table "expert" e = K range
     const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)wexp, 0, (unsigned)p.w_expert_stride, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)wexp, 0, ksp ? (unsigned)(p.w_bytes_total - (int64_t)e * p.w_expert_stride) : (unsigned)p.w_expert_stride, 0x00020000);
+    const unsigned x_koff = ksp ? (unsigned)e * (unsigned)p.C * 2u : 0u;   // bytes into every row of x
     unsigned xsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         } else {
             xrow = (int64_t)(pos0 + rr) * p.x_stride;
         }
-        xsrc[i] = (unsigned)(xrow * 2) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) << 4);   // image swizzle: chunk ^ ((row>>1)&7)
+        xsrc[i] = (unsigned)(xrow * 2) + x_koff + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) << 4);   // image swizzle: chunk ^ ((row>>1)&7)
         // rows past the tile's last one: an offset outside the descriptor's range.  The load still counts in vmcnt
         // (the stage waits are literals) but fetches nothing, so a tail tile with 40 rows does not pull 256 rows
         // through L2; whatever the LDS rows then hold only reaches accumulator columns that are never stored.
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     }
     unsigned wsrc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * ctiles) * 1024u + lane * 16;
+    for (int i = 0; i < 2; ++i) wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * (ksp ? p.c_full >> 6 : ctiles)) * 1024u + lane * 16;
 
     // one of the wave's six 1-KiB LDS-DMA pieces of stage kt (0..3: X rows, 4..5: packed W tiles).  The pieces of a
     // stage are issued ONE PER MFMA GROUP, never as a burst: a buffer_load...lds costs the issuing wave 60-180 cycles,
@@ -628,6 +631,12 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i] * sc_w;
                     const int col = wn * (NRT * 32) + rt * 32 + rg * 8 + he * 4;
+                    if (MODE == MODE_PLAIN && p.ksplit > 1) {   // split-K: this range's fp32 partial sums, reduced by the caller
+                        if (r < rows)
+                            *reinterpret_cast<float4*>(p.partial + ((int64_t)e * p.split_rows + pos0 + r) * p.out_cols + ntile * kCols + col) =
+                                make_float4(o4[0], o4[1], o4[2], o4[3]);
+                        continue;
+                    }
                     if (MODE == MODE_PLAIN) {   // dense epilogue: + bias[col] + addend[row][col] * scale, in fp32
                         const int gc = ntile * kCols + col;
                         if (p.bias) {
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
         const int r = idx / kChunksPerRow;
         const int pc = idx - r * kChunksPerRow;                 // physical chunk
         const int lc = pc ^ (r & 15);                           // logical chunk = 8 columns
-        if (r < rows) {
+        if (r < rows && !(MODE == MODE_PLAIN && p.ksplit > 1)) {
             const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
             int64_t orow;
             if (MODE == MODE_DOWN) orow = (int64_t)slot_tab[r] * p.out_stride + ntile * kCols;

@@ -38,6 +38,11 @@ struct MoeGemmParams {
     // partial [range][row][out_cols] reduced by launch_splitk_reduce; ksplit <= 1: whole reduction, bf16 out (+ bias)
     int ksplit, split_kblocks, split_rows, out_cols;
     float* partial;
+    // PLAIN on the 256-row kernel with split-K (dense GEMMs whose tiles would not fill the chip): the tile table's "expert" is
+    // the K range; C = the range's length, c_full = the whole reduction length (row stride of the packed weight / scale table),
+    // w_expert_stride = bytes of one range inside a row tile, w_bytes_total = extent of the weight for the buffer descriptor
+    int c_full;
+    int64_t w_bytes_total;
     int* tickets;                 // persistent 256-tile kernel: 8 zeroed counters (one per XCD) or null = static tile split
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
@@ -225,6 +230,7 @@ int generic_ksplit(int M, int N, int K);
 int launch_gemm_generic(int mode, const GenericGemmParams& p, int max_mtiles, hipStream_t stream);
 // the ordered reduce of split-K partials alone (fields used: partial, ksplit, split_rows, n_out, out, out_type, out_stride,
 // bias, addend*)
+int launch_dense_tiles_ksplit(int M, int tile_m, int ksplit, int4* tile_info, int* num_tiles, int* identity_slots, hipStream_t stream);
 int launch_splitk_reduce(const GenericGemmParams& p, hipStream_t stream);
 // partial != nullptr after a dense GEMM call: the call left its fp32 split-K partials [ksplit][rows][n] un-reduced (see
 // set_splitk_capture); else the GEMM wrote its bf16 output itself
