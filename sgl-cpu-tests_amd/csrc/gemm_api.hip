@@ -622,6 +622,27 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         q.M = M;
         q.K = K;
         q.n_tiles = N / 256;
+        const int kt = tuned_fp8_ksplit(M, N, K);         // the same policy as the fp8 tile kernel: long ranges, under-filled chip
+        if (kt > 1 && w.partial && (K / kt) % 32 == 0 && K / kt >= 128) {
+            q.K = K / kt;
+            q.k_full = K;
+            q.ksplit = kt;
+            q.out_cols = N;
+            q.partial = (float*)(ws + w.partial);
+            q.bias = nullptr;
+            rc = launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
+            if (rc != SGLK_OK) return rc;
+            GenericGemmParams r{};
+            r.partial = q.partial;
+            r.ksplit = kt;
+            r.split_rows = M;
+            r.n_out = N;
+            r.out = a->out;
+            r.out_type = SGLK_OUT_BF16;
+            r.out_stride = a->out_stride;
+            r.bias = a->bias;
+            return launch_splitk_reduce(r, s);
+        }
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
     }
     // W8A8 at decode sizes (M <= 128): weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)

@@ -43,7 +43,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
 
-    int live, e = 0, pos0, rows, mtile, ntile;
+    int live, e = 0, pos0, rows, mtile, ntile, ksr = 0;
+    const bool ksp = MODE == MODE_PLAIN && !p.tile_info && p.ksplit > 1;   // dense split-K
     if (p.tile_info) {   // grouped: m-tile table of moe_align (tile_m = 256)
         live = p.num_tiles[0] * p.n_tiles;
         if ((int)blockIdx.x >= live) return;
@@ -56,10 +57,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
         rows = __builtin_amdgcn_readfirstlane(ti.z);
     } else {             // dense: rows in natural order
         const int mtiles = (p.M + kBM - 1) / kBM;
-        live = mtiles * p.n_tiles;
+        const int nks = ksp ? p.ksplit : 1;
+        live = mtiles * p.n_tiles * nks;
         if ((int)blockIdx.x >= live) return;
         // consecutive workgroups of an XCD share the activation rows (same m-tile) and walk the weight row tiles
-        const int L = xcd_remap(blockIdx.x, live);
+        const int L0 = xcd_remap(blockIdx.x, live);
+        ksr = L0 % nks;                                   // K range of this workgroup (ranges fastest)
+        const int L = L0 / nks;
         mtile = L / p.n_tiles;
         ntile = L - mtile * p.n_tiles;
         pos0 = mtile * kBM;
@@ -89,7 +93,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)e * p.w_bytes), 0, (unsigned)p.w_bytes, 0x00020000);
-    const int kpairs = p.K >> 1;   // k pairs per row = dwords per row of a 32-row block
+    const int kpairs = (ksp ? p.k_full : p.K) >> 1;   // k pairs per row = dwords per row of a 32-row block
+    const unsigned x_koff = ksp ? (unsigned)ksr * (unsigned)p.K * 2u : 0u;             // this range's first column of x, bytes
+    const unsigned w_koff = ksp ? (unsigned)ksr * (unsigned)(p.K >> 1) * 128u : 0u;    // ... and k pair of a row block, bytes
     // X piece i of the wave (i = 0,1): image rows (wave*2+i)*16 + (lane>>2), LDS chunk lane&3 <- source chunk ^ swizzle
     unsigned xsrc[2], wsrc[2];
 #pragma unroll
@@ -98,9 +104,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
         const int rr = r < rows ? r : 0;
         int64_t xrow = pos0 + rr;
         if (MODE == MODE_GATE_UP) xrow = p.sorted_slot[pos0 + rr] / p.topk;
-        xsrc[i] = (unsigned)(xrow * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+        xsrc[i] = (unsigned)(xrow * p.x_stride) + x_koff + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
         // W piece wave*2+i = row block `wave`, half i of the stage's 16 k pairs (8 pairs x 128 B = 1 KiB)
-        wsrc[i] = (unsigned)(row_block(wave) * kpairs) * 128u + (unsigned)i * 1024u + lane * 16;
+        wsrc[i] = (unsigned)(row_block(wave) * kpairs) * 128u + w_koff + (unsigned)i * 1024u + lane * 16;
     }
     auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // i = 0,1: X rows; 2,3: packed W tiles
         unsigned char* sx = smem + buf * kStage;
@@ -305,6 +311,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
                         float o4[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o4[i] = acc[rt][tt][rg * 4 + i];
+                        if (ksp) {   // this range's fp32 partial sums; the caller's ordered reduce adds the bias
+                            if (r < rows)
+                                *reinterpret_cast<float4*>(p.partial + ((int64_t)ksr * p.M + pos0 + r) * p.out_cols + ntile * 256 + col) =
+                                    make_float4(o4[0], o4[1], o4[2], o4[3]);
+                            continue;
+                        }
                         if (MODE == MODE_PLAIN) {
                             const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + col);
                             o4[0] += b4.x; o4[1] += b4.y; o4[2] += b4.z; o4[3] += b4.w;
@@ -329,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
         const int r = idx / kChunksPerRow;
         const int pc = idx - r * kChunksPerRow;
         const int lc = pc ^ (r & 15);                  // logical chunk: 8 bf16 columns
-        if (r < rows) {
+        if (r < rows && !ksp) {
             const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
             const int64_t orow = (MODE == MODE_DOWN) ? (int64_t)slot_tab[r] : (int64_t)(pos0 + r);
             *reinterpret_cast<uint4*>(p.out + orow * p.out_stride + ntile * kCols + lc * 8) = v;
@@ -516,9 +528,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_256w4_kernel(const Bf16GemmPara
 
 int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream) {
     if (p.K < 128 || p.K % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_bf16_256: reduction length %d must be a multiple of 32 and >= 128", p.K);
-    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles * ((mode == MODE_PLAIN && !p.tile_info && p.ksplit > 1) ? p.ksplit : 1);
     if (blocks <= 0) return SGLK_OK;
-    const bool w4 = knobs().bf16_w4;
+    const bool w4 = knobs().bf16_w4 && p.ksplit <= 1;
     if (w4 && mode == MODE_PLAIN && !p.tile_info) {
         hipLaunchKernelGGL(gb16::gemm_bf16_256w4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
         SGLK_CHECK_LAUNCH("gemm_bf16_256w4");

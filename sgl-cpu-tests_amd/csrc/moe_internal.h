@@ -137,6 +137,10 @@ struct Bf16GemmParams {
     int topk;
     int n_half;               // GATE_UP: N
     const float* topk_weights;   // DOWN
+    // dense PLAIN with split-K (tiles that would not fill the chip): K = the length of one range, k_full = the whole reduction
+    // (row-block stride of the packed weight), workgroup = (m-tile, column tile, range); fp32 partial [range][M][out_cols]
+    int ksplit, k_full, out_cols;
+    float* partial;
 };
 int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream);
 
