@@ -35,11 +35,11 @@ bool dense_prefers_mid(int M, int N, int wtype) {
 // Split-K for the 256-row fp8 tile kernel in dense mode: with ceil(M / 256) x N / 256 workgroups well under the CU count the
 // launch takes one tile's time on a part of the chip; K ranges (fp32 partials, ordered reduce) fill it.  Ranges are whole
 // 128-wide blocks, at least sixteen per range, as many ranges as keep the workgroup count within ~1.25 x the CUs.
-int tuned_fp8_ksplit(int M, int N, int K) {
+int tuned_fp8_ksplit(int M, int N, int K, int fill = 2) {   // split only when the tiles fill at most 1 / fill of the chip
     if (knobs().no_tuned_splitk || N % 256 != 0 || K % 128 != 0) return 1;
     const int64_t wgs = ceil_div(M, 256) * (int64_t)(N / 256);
     const int cus = device_cu_count(), kb = K >> 7;
-    if (wgs * 2 > cus) return 1;
+    if (wgs * fill > cus) return 1;
     int best = 1;
     for (int ks = 2; ks <= 8; ++ks) {
         if (kb % ks != 0 || kb / ks < 16) continue;   // shorter ranges lose to the fp32 partial round trip (4096 x 1536 x 2048: 0.051 -> 0.056 ms)
@@ -714,6 +714,20 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
             q.M = M;
             q.K = K;
             q.n_tiles = N / 256;
+            // under-filled launch, long ranges: exact int32 partials per K range.  The int8 tiles are twice as fast, so the partials'
+            // round trip only pays below an eighth of the chip (1024 x 2048 x 6144: 0.066 -> 0.051 ms; 2048 x 4096 x 4096 would lose)
+            const int kt = tuned_fp8_ksplit(M, N, K, 8);
+            if (kt > 1 && w.partial) {
+                q.K = K / kt;
+                q.N = N;
+                q.ksplit = kt;
+                q.split_kblocks = (K / kt) >> 7;
+                q.partial_i32 = (int32_t*)(ws + w.partial);
+                q.out_type = SGLK_OUT_BF16;
+                rc = launch_gemm_i8_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
+                if (rc != SGLK_OK) return rc;
+                return launch_i8_splitk_reduce(q, s);
+            }
             return launch_gemm_i8_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
         }
     }

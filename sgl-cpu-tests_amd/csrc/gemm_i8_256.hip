@@ -53,7 +53,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 3, wm = wave >> 2;
 
-    int live, e = 0, pos0, rows, mtile, ntile;
+    int live, e = 0, pos0, rows, mtile, ntile, ksr = 0;
+    // dense split-K (launches that would not fill the chip): workgroup = (m-tile, column tile, K range), exact int32 partials
+    const bool ksp = MODE == MODE_PLAIN && !p.tile_info && p.ksplit > 1;
     if (p.tile_info) {   // grouped: m-tile table of moe_align (tile_m = 256)
         live = p.num_tiles[0] * p.n_tiles;
         if ((int)blockIdx.x >= live) return;
@@ -66,10 +68,13 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
         rows = __builtin_amdgcn_readfirstlane(ti.z);
     } else {             // dense: rows in natural order
         const int mtiles = (p.M + kBM - 1) / kBM;
-        live = mtiles * p.n_tiles;
+        const int nks = ksp ? p.ksplit : 1;
+        live = mtiles * p.n_tiles * nks;
         if ((int)blockIdx.x >= live) return;
         // consecutive workgroups of an XCD share the activation rows (same m-tile) and walk the weight row tiles
-        const int L = xcd_remap(blockIdx.x, live);
+        const int L0 = xcd_remap(blockIdx.x, live);
+        ksr = L0 % nks;
+        const int L = L0 / nks;
         mtile = L / p.n_tiles;
         ntile = L - mtile * p.n_tiles;
         pos0 = mtile * kBM;
@@ -114,7 +119,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)e * p.w_bytes), 0, (unsigned)p.w_bytes, 0x00020000);
-    const int ctiles = p.K >> 6;
+    const int ctiles = (ksp ? p.split_kblocks * p.ksplit * 2 : p.K >> 6);   // 64-wide tiles per weight row (whole reduction)
+    const unsigned x_koff = ksp ? (unsigned)ksr * (unsigned)p.K : 0u;                 // bytes into every row of x
+    const unsigned w_koff = ksp ? (unsigned)ksr * (unsigned)(p.K >> 6) * 1024u : 0u;  // this range's first tile of a row tile
     // X piece i of the wave (i = 0,1): image rows (wave*2+i)*16 + (lane>>2), LDS chunk lane&3 <- source chunk ^ swizzle
     unsigned xsrc[2], wsrc[2];
 #pragma unroll
@@ -123,8 +130,8 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
         const int rr = r < rows ? r : 0;
         int64_t xrow = pos0 + rr;
         if (MODE == MODE_GATE_UP) xrow = p.sorted_slot[pos0 + rr] / p.topk;
-        xsrc[i] = (unsigned)(xrow * p.x_stride) + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
-        wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * ctiles) * 1024u + lane * 16;
+        xsrc[i] = (unsigned)(xrow * p.x_stride) + x_koff + (unsigned)((((lane & 3) ^ ((r >> 2) & 3))) << 4);
+        wsrc[i] = (unsigned)(piece_row16(wave * 2 + i) * ctiles) * 1024u + w_koff + lane * 16;
     }
     auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // i = 0,1: X rows; 2,3: packed W tiles
         unsigned char* sx = smem + buf * kStage;
@@ -340,6 +347,12 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) {
                         const int r = wm * 128 + tt * 32 + r32;
+                        if (ksp) {   // this range's exact int32 sums; scales and bias are applied by the reduce
+                            if (r < rows)
+                                *reinterpret_cast<int4*>(p.partial_i32 + ((int64_t)ksr * p.M + pos0 + r) * p.N + ntile * 256 + col) =
+                                    make_int4(acc[rt][tt][rg * 4 + 0], acc[rt][tt][rg * 4 + 1], acc[rt][tt][rg * 4 + 2], acc[rt][tt][rg * 4 + 3]);
+                            continue;
+                        }
                         const float xs = xs4[tt];
                         float o4[4];   // (xs * acc) * ws (+ bias | * routing weight), separately rounded like the oracle
                         o4[0] = xs * (float)acc[rt][tt][rg * 4 + 0] * w4.x;
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
         const int r = idx / kChunksPerRow;
         const int pc = idx - r * kChunksPerRow;
         const int lc = pc ^ (r & 15);                  // logical chunk: 8 bf16 or 4 fp32 columns
-        if (r < rows) {
+        if (r < rows && !ksp) {
             const uint4 v = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
             if (MODE == MODE_GATE_UP) {
                 float* orow = reinterpret_cast<float*>(p.out) + (int64_t)(pos0 + r) * p.out_stride + ntile * 128;
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
 
 int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream) {
     if (p.K < 256 || p.K % 64 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_256: reduction length %d must be a multiple of 64 and >= 256", p.K);
-    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    const int64_t blocks = (int64_t)max_mtiles * p.n_tiles * ((mode == MODE_PLAIN && !p.tile_info && p.ksplit > 1) ? p.ksplit : 1);
     if (blocks <= 0) return SGLK_OK;
     if (mode == MODE_GATE_UP) hipLaunchKernelGGL(gi8::gemm_i8_256_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), 0, stream, p);
     else if (mode == MODE_DOWN) hipLaunchKernelGGL(gi8::gemm_i8_256_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), 0, stream, p);

@@ -337,6 +337,17 @@ int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
     return SGLK_OK;
 }
 
+// the ordered reduce of exact int32 split-K partials [ksplit][M][N] with the oracle's float operations (also behind the 256-row
+// int8 kernel's dense split-K)
+int launch_i8_splitk_reduce(const I8GemmParams& q, hipStream_t stream) {
+    int64_t rb = ceil_div((int64_t)q.M * q.N, 256);
+    if (rb > 2048) rb = 2048;
+    if (rb <= 0) return SGLK_OK;
+    hipLaunchKernelGGL(gimid::i8_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, q);
+    SGLK_CHECK_LAUNCH("int8 split-K reduce");
+    return SGLK_OK;
+}
+
 // tile table built with tile_m = kI8MidTileM; GATE_UP: n_tiles = N / 128, out = fp32 ic1 [position][N]; DOWN: n_tiles = R / 128,
 // out = bf16 ic2 [slot][R]
 int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream) {

@@ -118,6 +118,7 @@ struct I8GemmParams {
     int out_type;             // PLAIN: SGLK_OUT_* of `out`
 };
 int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
+int launch_i8_splitk_reduce(const I8GemmParams& q, hipStream_t stream);   // [ksplit][M][N] int32 partials -> out (scales, bias)
 
 // ---- bf16 GEMM with VNNI-2 packed weights on the bf16 matrix cores (gemm_bf16_256.hip) ------------------------------------
 struct Bf16GemmParams {
