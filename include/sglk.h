@@ -150,7 +150,8 @@ enum {
     SGLK_PATH_PERSIST_G2 = 0x10000,   /* GEMM-2 launched persistent */
     SGLK_PATH_ROUTE_ALIGN = 0x20000,  /* sglk_moe_block: router + align ran as one launch */
     SGLK_PATH_SHARED_FOLDED = 0x40000,/* sglk_moe_block: routed combine folded into the shared expert's last launch */
-    SGLK_PATH_SPLIT = 0x80000         /* W8A16 with the activations as two exact e4m3 terms on the scaled fp8 MFMA */
+    SGLK_PATH_SPLIT = 0x80000,        /* W8A16 with the activations as two exact e4m3 terms on the scaled fp8 MFMA */
+    SGLK_PATH_INLINE_ALIGN = 0x100000 /* at most 32 slots: no moe_align launch, the GEMM workgroups sort the ids themselves */
 };
 
 size_t sglk_fused_experts_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t E, int32_t topk, int32_t wtype);

@@ -56,6 +56,7 @@ void read_env() {
     k.mxfp4_native = env_int("SGLK_MXFP4_NATIVE", -1);
     k.mxfp4_rt = env_int("SGLK_MXFP4_RT", 4);
     k.no_pack_on_the_fly = env_set("SGLK_NO_PACK_ON_THE_FLY");
+    k.inline_align_max = env_int("SGLK_INLINE_ALIGN_MAX", 16);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
     k.split = env_int("SGLK_SPLIT", -1);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);

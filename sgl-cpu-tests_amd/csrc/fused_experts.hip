@@ -2,6 +2,7 @@
 // Operator contract: /root/reference/bench_moe.py:113-130 (14-arg), /root/reference/test_moe.py:79-92 (13-arg).
 #include "knobs.h"
 #include "moe_internal.h"
+#include "moe_align_inline.h"
 
 #include <stdlib.h>
 
@@ -295,7 +296,12 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         }
         if (rc != SGLK_OK) return rc;
     }
-    if (!routed_and_aligned)
+    // decode sizes on the weight-streaming kernel: no align launch at all -- its workgroups sort the (at most 32) ids themselves
+    // (moe_align_inline.h).  Four dependent launches become three: M = 1 (8 slots) 33.7 -> 30.5 us as a hipGraph replay; at 32 slots
+    // the sort costs what the launch did, hence 16 (SGLK_INLINE_ALIGN_MAX, 0 = off).
+    const int inline_max = knobs().inline_align_max < kInlineAlignSlots ? knobs().inline_align_max : kInlineAlignSlots;
+    const bool inline_align = tuned && !a8 && tile_m == kStreamTileM && !route && !split_tails && (int64_t)M * topk <= inline_max;
+    if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
                                     w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets));
@@ -515,6 +521,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g1.out = ic1;
         g1.out_stride = N;
         g1.topk_weights = nullptr;
+        if (inline_align) { g1.inline_ids = a->topk_ids; g1.inline_slots = M * topk; g1.inline_experts = E; }
         // per-XCD tile tickets of the two persistent launches (8 counters each), zeroed per call by moe_align's last launch
         if (tile_m == 256) g1.tickets = (int*)(ws + w.tickets);
 #ifdef SGLK_DEV_ABLATE
@@ -593,6 +600,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g2.n_half = 0;
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
+        if (inline_align) { g2.inline_ids = a->topk_ids; g2.inline_slots = M * topk; g2.inline_experts = E; }
         // mid kernel, DOWN: two 128-column tiles per workgroup on one weight ring when the shapes allow (SGLK_MID_DOWN2=0: one)
         const bool mid_down2 = tile_m == kMidTileM && N % 256 == 0 && K % 256 == 0 && knobs().mid_down2 != 0;
         g2.n_tiles = (tile_m == 128 || (tile_m == kMidTileM && !mid_down2)) ? K / 128 : K / 256;
@@ -907,7 +915,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
             if (moe_gemm_fp8w_256i_is_persistent(K, (int64_t)max_tiles * (N / 128))) path |= SGLK_PATH_PERSIST_G1;
             if (moe_gemm_fp8w_256i_is_persistent(N, (int64_t)max_tiles * (K / 256))) path |= SGLK_PATH_PERSIST_G2;
         }
-        *a->path_taken = path | (routed_and_aligned ? SGLK_PATH_ROUTE_ALIGN : 0) | (shared ? SGLK_PATH_SHARED_FOLDED : 0);
+        *a->path_taken = path | (inline_align ? SGLK_PATH_INLINE_ALIGN : 0) | (routed_and_aligned ? SGLK_PATH_ROUTE_ALIGN : 0) | (shared ? SGLK_PATH_SHARED_FOLDED : 0);
     }
     return rc;
 }

@@ -34,6 +34,7 @@ struct Knobs {
     int mxfp4_rt = 4;            // SGLK_MXFP4_RT: 32-row tiles per wave of the fp4-MFMA kernel (4 / 2; A/B)
     int mxfp4_native = -1;       // SGLK_MXFP4_NATIVE: 1 / 0 = fp4-MFMA kernel for every legal shape / never; unset = by tile count
     int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
+    int inline_align_max = 16;   // SGLK_INLINE_ALIGN_MAX: fused_experts with at most this many slots (<= 32) sorts the ids in the GEMM kernels, no moe_align launch; 0 = never (A/B)
     bool no_block_fold = false;  // SGLK_NO_BLOCK_FOLD: sglk_moe_block runs router / align / combine / shared expert unfused (A/B)
     int split = -1;              // SGLK_SPLIT: 0 = bf16-MFMA 256-row kernel, 1 = two-term e4m3 split on the scaled fp8 MFMA; unset = default
     int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)

@@ -15,6 +15,7 @@
 // * fp8 -> bf16 exactly (v_cvt_scalef32_pk_bf16_fp8, scale 1.0), per-128-K-block partial accumulator scaled in fp32.
 #include "knobs.h"
 #include "moe_internal.h"
+#include "moe_align_inline.h"
 
 namespace sglk {
 namespace gstream {
@@ -41,15 +42,28 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeG
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const int live = p.num_tiles[0] * p.n_tiles;
+    // tile table: moe_align's, or (p.inline_ids, at most 32 slots) derived here by every wave from the ids themselves
+    __shared__ int slot_tab[kInlineAlignSlots];   // inline form: slot of the tile's row r
+    const bool inl = p.inline_ids != nullptr;
+    InlineAlign ia{};
+    if (inl) ia = inline_align(p.inline_ids, p.inline_slots, p.inline_experts, lane);
+    const int live = (inl ? ia.ntiles : p.num_tiles[0]) * p.n_tiles;
     if ((int)blockIdx.x >= live) return;
     const int L = xcd_remap(blockIdx.x, live);
     const int mtile = L / p.n_tiles;
     const int ntile = L - mtile * p.n_tiles;
-    const int4 ti = p.tile_info[mtile];
-    const int e = __builtin_amdgcn_readfirstlane(ti.x);
-    const int pos0 = __builtin_amdgcn_readfirstlane(ti.y);
-    const int rows = __builtin_amdgcn_readfirstlane(ti.z);
+    int e, pos0, rows;
+    if (inl) {
+        const InlineTile it = inline_tile(ia, mtile, lane, wave == 0, slot_tab);   // exactly one expert: mtile < ntiles
+        e = it.e; pos0 = it.pos0; rows = it.rows;
+        __syncthreads();
+    } else {
+        const int4 ti = p.tile_info[mtile];
+        e = __builtin_amdgcn_readfirstlane(ti.x);
+        pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+        rows = __builtin_amdgcn_readfirstlane(ti.z);
+    }
+    auto slot_of = [&](int r) __attribute__((always_inline)) { return inl ? slot_tab[r] : p.sorted_slot[pos0 + r]; };
 
     const int C = p.C;
     const int ctiles = C >> 6;           // 64-wide pieces along the reduction dim
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeG
             uint4 v = make_uint4(0, 0, 0, 0);
             if (r < rows) {
                 int64_t xrow;
-                if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[pos0 + r] / p.topk) * p.x_stride;
+                if (MODE == MODE_GATE_UP) xrow = (int64_t)(slot_of(r) / p.topk) * p.x_stride;
                 else xrow = (int64_t)(pos0 + r) * p.x_stride;
                 v = *reinterpret_cast<const uint4*>(p.x + xrow + ch * 8);
             }
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeG
             v.y = pack_bf16x2(silu_f32(gt[2]) * up[2], silu_f32(gt[3]) * up[3]);
             *reinterpret_cast<uint2*>(p.out + (int64_t)(pos0 + tr) * p.out_stride + ntile * 128 + wave * 16 + q4) = v;
         } else {
-            const int slot = p.sorted_slot[pos0 + tr];
+            const int slot = slot_of(tr);
             const float tw = p.topk_weights[slot];
             uint16_t* orow = p.out + (int64_t)slot * p.out_stride + ntile * 256 + wave * 32 + q4;
 #pragma unroll

@@ -44,6 +44,9 @@ struct MoeGemmParams {
     int c_full;
     int64_t w_bytes_total;
     int* tickets;                 // persistent 256-tile kernel: 8 zeroed counters (one per XCD) or null = static tile split
+    // weight-streaming kernel, at most 32 slots: no moe_align launch -- every workgroup sorts the ids itself (moe_align_inline.h)
+    const int* inline_ids;        // topk_ids [inline_slots] or null = tile_info / num_tiles / sorted_slot tables
+    int inline_slots, inline_experts;
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup {shader clocks, 100 MHz ticks}
 };
 

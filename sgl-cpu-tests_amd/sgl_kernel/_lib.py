@@ -10,7 +10,7 @@ MOE_FP8_ACT = 1                      # sglk_fused_experts_args.flags
 MOE_PACK_WEIGHTS = 2                 # row-major weights: re-tile them into the workspace, run the packed kernels
 PATH_TILE_MASK, PATH_FP8_ACT, PATH_TAILS_SPLIT, PATH_TAILS_AUX, PATH_PERSIST_G1, PATH_PERSIST_G2 = (
     0x3ff, 0x1000, 0x2000, 0x4000, 0x8000, 0x10000)
-PATH_ROUTE_ALIGN, PATH_SHARED_FOLDED, PATH_SPLIT = 0x20000, 0x40000, 0x80000
+PATH_ROUTE_ALIGN, PATH_SHARED_FOLDED, PATH_SPLIT, PATH_INLINE_ALIGN = 0x20000, 0x40000, 0x80000, 0x100000
 
 
 class FusedExpertsArgs(ctypes.Structure):

@@ -239,3 +239,23 @@ def test_fused_experts_fp8_rowmajor_weights_are_retiled_at_prefill_sizes(ops):
             assert torch.equal(packed, rowmajor)
         ref = moe.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
         check_close(rowmajor, ref, f"row-major M={M}")
+
+
+@pytest.mark.parametrize("M,topk,masked", [(1, 8, False), (3, 8, True), (4, 8, False), (4, 8, True), (16, 2, True), (32, 1, False)])
+def test_fused_experts_fp8_decode_sizes_sort_ids_in_the_gemm_kernels(ops, M, topk, masked, knob):
+    """At most 32 slots: no moe_align launch, the weight-streaming kernels derive their tile from topk_ids themselves
+    (moe_align_inline.h).  Same bits as with the align launch, and the oracle's values; -1 ids skipped as in
+    /root/reference/test_moe_offloading_cpu.py:62-68; several tokens on one expert."""
+    from sgl_kernel import _lib, _ops
+    N, K, E, bn, bk = 256, 512, 12, 128, 128      # twelve experts: tokens share experts
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, 4242 + M)
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk),
+                                     inp["topk_weight"], inp["topk_ids"])
+    knob(SGLK_INLINE_ALIGN_MAX=32)     # the default stops at 16 slots (where it pays); the kernels take 32
+    out, _ = run_fp8(ops, inp, (bn, bk))
+    assert _ops.last_path & _lib.PATH_INLINE_ALIGN and (_ops.last_path & _lib.PATH_TILE_MASK) == 32
+    check_close(out, ref, f"inline align M={M} topk={topk}")
+    knob(SGLK_INLINE_ALIGN_MAX=0)
+    out_t, _ = run_fp8(ops, inp, (bn, bk))
+    assert not (_ops.last_path & _lib.PATH_INLINE_ALIGN)
+    assert torch.equal(out, out_t)
