@@ -17,18 +17,31 @@ constexpr int kEpMaxRanks = 16;
 // Workgroup b plans tokens [1024 b, 1024 b + 1024).  It needs the number of earlier tokens per destination; instead of a
 // chained scan over workgroups it simply RE-COUNTS them (all 1024 threads over the ids of tokens [0, 1024 b): at most 512 KB
 // from L2 at M = 16384): one launch, no inter-workgroup synchronisation, deterministic.
-__global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ ids, int M, int topk, int E, int G, int epr,
+// destination of an expert id without an integer division (8 per token, 16 tokens per thread in the last workgroup: they were most
+// of the kernel's 158 us at M = 16384): (e + 0.5) / epr is at least 0.5 / epr away from an integer, far more than fp32 rounding
+SGLK_DEV unsigned ep_dest_bit(int e, int E, float inv_epr) {
+    return (unsigned)e < (unsigned)E ? 1u << (int)(((float)e + 0.5f) * inv_epr) : 0u;
+}
+
+template <bool VEC4>   // VEC4: topk % 4 == 0 and 16-byte aligned ids -> one int4 per four slots
+__global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ ids, int M, int topk, int E, int G, float inv_epr,
                                                        int capacity, int* __restrict__ counts, int* __restrict__ seg_start,
                                                        int* __restrict__ pos, int* __restrict__ overflow) {
     __shared__ int wave_tot[16][kEpMaxRanks];
     __shared__ int base_s[kEpMaxRanks];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int first = blockIdx.x * 1024;
-    auto mask_of = [&](int m) {
+    auto mask_of = [&](int m) __attribute__((always_inline)) {
         unsigned mask = 0;
-        for (int j = 0; j < topk; ++j) {
-            const int e = ids[(int64_t)m * topk + j];
-            if (e >= 0 && e < E) mask |= 1u << (e / epr);
+        if (VEC4) {
+            const int4* row = reinterpret_cast<const int4*>(ids + (int64_t)m * topk);
+            for (int j = 0; j < (topk >> 2); ++j) {
+                const int4 v = row[j];
+                mask |= ep_dest_bit(v.x, E, inv_epr) | ep_dest_bit(v.y, E, inv_epr) | ep_dest_bit(v.z, E, inv_epr) |
+                        ep_dest_bit(v.w, E, inv_epr);
+            }
+        } else {
+            for (int j = 0; j < topk; ++j) mask |= ep_dest_bit(ids[(int64_t)m * topk + j], E, inv_epr);
         }
         return mask;
     };
@@ -152,8 +165,14 @@ extern "C" int sglk_ep_plan(const int32_t* topk_ids, int32_t M, int32_t topk, in
     SGLK_REQUIRE(counts && seg_start && pos && overflow && (M == 0 || topk_ids), SGLK_ERR_INVALID, "ep_plan: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(overflow, 0, sizeof(int), s) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "ep_plan: memset failed");
-    hipLaunchKernelGGL(ep_plan_kernel, dim3((unsigned)(M > 0 ? ceil_div(M, 1024) : 1)), dim3(1024), 0, s, topk_ids, M, topk, E, G, E / G,
-                       capacity, counts, seg_start, pos, overflow);
+    const dim3 grid((unsigned)(M > 0 ? ceil_div(M, 1024) : 1));
+    const float inv_epr = 1.0f / (float)(E / G);
+    if (topk % 4 == 0 && ((uintptr_t)topk_ids % 16) == 0)
+        hipLaunchKernelGGL(ep_plan_kernel<true>, grid, dim3(1024), 0, s, topk_ids, M, topk, E, G, inv_epr, capacity, counts, seg_start, pos,
+                           overflow);
+    else
+        hipLaunchKernelGGL(ep_plan_kernel<false>, grid, dim3(1024), 0, s, topk_ids, M, topk, E, G, inv_epr, capacity, counts, seg_start, pos,
+                           overflow);
     SGLK_CHECK_LAUNCH("ep_plan");
     return SGLK_OK;
 }
