@@ -1,0 +1,79 @@
+"""Randomised parity sweep of the fp8 (W8A16) fused_experts paths against the plain-C oracle (test infrastructure, not a
+benchmark): random shapes, expert counts, routing (incl. -1 ids and skewed loads), block sizes, packed / row-major weights,
+in-place or not.  Every kernel choice of the library (stream / mid / 128 / 256-row, generic engine) is hit by shape alone.
+usage: python tools/fuzz_moe.py [iterations] [seed]      -> one line per failure, a summary line at the end"""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import sgl_kernel  # noqa: F401,E402
+from sgl_kernel import _lib, _ops  # noqa: E402
+import recipes  # noqa: E402
+from oracle import c_oracle  # noqa: E402
+
+ops = torch.ops.sgl_kernel
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
+fails, paths = 0, {}
+
+
+def routing(M, E, topk, kind, g):
+    if kind == "softmax":
+        return recipes.routing_softmax_topk(M, E, topk, g)
+    if kind == "skewed":       # most tokens on two experts
+        score = torch.randn(M, E, generator=g)
+        score[:, : min(2, E)] += 6.0
+        tw, ids = torch.topk(torch.softmax(score, -1), topk)
+        return tw, ids.to(torch.int32)
+    ids = torch.randint(0, E, (M, topk), generator=g, dtype=torch.int32)     # masked, repeats allowed
+    ids[torch.rand(M, topk, generator=g) < 0.4] = -1
+    return torch.randn(M, topk, generator=g), ids
+
+
+for it in range(iters):
+    N = rng.choice([128, 256, 384, 512, 768])
+    K = rng.choice([128, 256, 512, 1024, 2048])
+    E = rng.choice([1, 2, 8, 16, 64])
+    topk = rng.choice([t for t in (1, 2, 4, 8) if t <= E])
+    M = rng.choice([1, 2, 3, 4, 7, 16, 33, 64, 100, 257, 600, 1500, 3000]) if E <= 16 else rng.choice([1, 4, 16, 64, 300, 1200])
+    while M > 1 and 6.0 * M * topk * N * K > 2.5e10:      # keep the scalar oracle to a second or two per case
+        M //= 2
+    bn = rng.choice([64, 128])
+    kind = rng.choice(["softmax", "softmax", "skewed", "masked"])
+    packed = rng.random() < 0.8
+    inplace = rng.random() < 0.5
+    g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    a = (torch.randn(M, K, generator=g) / K ** 0.5).bfloat16()
+    w1, w2 = recipes.fp8_weight((E, 2 * N, K), g), recipes.fp8_weight((E, K, N), g)
+    w1s = torch.randn(E, 2 * N // bn, K // 128, generator=g) * recipes.SCALE_FACTOR
+    w2s = torch.randn(E, K // bn, N // 128, generator=g) * recipes.SCALE_FACTOR
+    tw, ids = routing(M, E, topk, kind, g)
+    ref = c_oracle.fused_experts_fp8(a, w1, w2, w1s, w2s, (bn, 128), tw, ids)
+    # outputs into the O(1) range the reference's atol = rtol = 1e-2 is meant for (its tests give |out| <~ 2; at |out| in [2, 4)
+    # two bf16 ulps already exceed it): the result is linear in the routing weights
+    k = 2.0 / max(float(ref.abs().max()), 1e-6)
+    tw, ref = tw * k, ref * k
+    d = [t.cuda() for t in (a, w1, w2, tw, ids, w1s, w2s)]
+    w1d, w2d = (ops.convert_weight_packed(d[1]), ops.convert_weight_packed(d[2])) if packed else (d[1], d[2])
+    out = ops.fused_experts_cpu(d[0], w1d, w2d, d[3], d[4], inplace, False, True, d[5], d[6], [bn, 128], None, None, packed)
+    torch.cuda.synchronize()
+    o = out.float().cpu()
+    ok_pred = torch.allclose(ref.bfloat16(), out.cpu(), rtol=1e-2, atol=1e-2)
+    rel = float((o - ref).norm() / ref.norm().clamp_min(1e-12))
+    path = _ops.last_path & _lib.PATH_TILE_MASK
+    paths[path] = paths.get(path, 0) + 1
+    if not ok_pred or rel > 6e-3 or not torch.isfinite(o).all():
+        fails += 1
+        diff = (o - ref.bfloat16().float()).abs()
+        bad = diff > 1e-2 + 1e-2 * o.abs()
+        print(f"FAIL it={it} M={M} N={N} K={K} E={E} topk={topk} bn={bn} {kind} packed={packed} inplace={inplace} "
+              f"path={_ops.last_path:#x} rel={rel:.2e} pred={ok_pred} bad={int(bad.sum())}/{bad.numel()} max|diff|={float(diff.max()):.4f} "
+              f"max|ref|={float(ref.abs().max()):.2f} max|tw|={float(tw.abs().max()):.2f}", flush=True)
+print(f"fuzz_moe fp8: {iters} cases, {fails} failures, tile paths {dict(sorted(paths.items()))}")
+sys.exit(1 if fails else 0)
