@@ -285,6 +285,108 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
             return launch_splitk_reduce(r, s);
         }
     }
+    // bf16 / int8 packed weights at prefill sizes: the tuned 256-row kernels of fused_experts -- gate_up + SiLU*mul in the grouped form with
+    // one "expert" and an identity row map, down in the dense form with fused_out * routed_scaling_factor added in fp32 before the
+    // single bf16 rounding.  (The generic engine took 0.71 ms (bf16) / 0.66 ms (int8) at 2048 x 2048 x 7168.)  Below
+    // SGLK_SHARED_MID_MAX rows the split-K passes further down are taken where they exist (their crossover is the fp8 one's).
+    const bool big_common = (a->packed & 3) == 3 && !moe && !knobs().force_generic && M >= 192 && N % 128 == 0 && K % 256 == 0 &&
+                            a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0 && a->fused_out_stride % 4 == 0 &&
+                            ((uintptr_t)a->fused_out % 8) == 0 && (int64_t)4 * N * K < (1ll << 32) && (int64_t)M * N * 4 < (1ll << 32);
+    if (big_common && a->wtype == SGLK_W_BF16 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
+        (int64_t)M * a->hidden_stride * 2 < (1ll << 32) &&
+        (M >= knobs().shared_mid_max || bf16_mid_ksplit(M, 2 * N, K) < 1 || bf16_mid_ksplit(M, K, N) < 1)) {
+        int* ident = (int*)(ws + w.ident);
+        const int t256 = (int)ceil_div(M, 256);
+        rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
+        if (rc != SGLK_OK) return rc;
+        Bf16GemmParams q1{};
+        q1.x = (const uint16_t*)a->hidden;
+        q1.x_stride = a->hidden_stride * 2;
+        q1.x_bytes = (int64_t)M * a->hidden_stride * 2;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_bytes = (int64_t)2 * N * K * 2;
+        q1.out = ic1;
+        q1.out_stride = N;
+        q1.M = M;
+        q1.K = K;
+        q1.n_tiles = N / 128;
+        q1.tile_info = tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = ident;
+        q1.topk = 1;
+        q1.n_half = N;
+        rc = launch_gemm_bf16_256(MODE_GATE_UP, q1, t256, s);
+        if (rc != SGLK_OK) return rc;
+        Bf16GemmParams q2{};
+        q2.x = ic1;
+        q2.x_stride = (int64_t)N * 2;
+        q2.x_bytes = (int64_t)M * N * 2;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_bytes = (int64_t)K * N * 2;
+        q2.out = (uint16_t*)a->out;
+        q2.out_stride = a->out_stride;
+        q2.M = M;
+        q2.K = N;
+        q2.n_tiles = K / 256;
+        q2.addend = (const uint16_t*)a->fused_out;
+        q2.addend_stride = a->fused_out_stride;
+        q2.addend_scale = a->routed_scaling_factor;
+        return launch_gemm_bf16_256(MODE_PLAIN, q2, t256, s);
+    }
+    if (big_common && i8 && N >= 256 && (int64_t)M * K < (1ll << 32) &&
+        (i8_mid_ksplit(M, 2 * N, K) < 1 || i8_mid_ksplit(M, K, N) < 1 || knobs().no_i8_mid)) {
+        int* ident = (int*)(ws + w.ident);
+        const int t256 = (int)ceil_div(M, 256);
+        rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
+        if (rc != SGLK_OK) return rc;
+        int8_t* xq = (int8_t*)(ws + w.xq);
+        float* xs = (float*)(ws + w.xs);
+        rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q1{};
+        q1.x = xq;
+        q1.x_stride = K;
+        q1.x_bytes = (int64_t)M * K;
+        q1.x_scale = xs;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_bytes = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = 2 * N;
+        q1.out = ic1;                  // fp32 [row][N]: SiLU*mul stays in fp32 until it is quantised
+        q1.out_stride = N;
+        q1.M = M;
+        q1.K = K;
+        q1.n_tiles = N / 128;
+        q1.tile_info = tile_info;
+        q1.num_tiles = num_tiles;
+        q1.sorted_slot = ident;
+        q1.topk = 1;
+        q1.n_half = N;
+        rc = launch_gemm_i8_256(MODE_GATE_UP, q1, t256, s);
+        if (rc != SGLK_OK) return rc;
+        int8_t* hq = (int8_t*)(ws + w.ic1q);
+        float* hs = (float*)(ws + w.ic1s);
+        rc = launch_quant_int8_rows_f32((const float*)ic1, N, hq, N, hs, M, N, 1e-7f, s);
+        if (rc != SGLK_OK) return rc;
+        I8GemmParams q2{};
+        q2.x = hq;
+        q2.x_stride = N;
+        q2.x_bytes = (int64_t)M * N;
+        q2.x_scale = hs;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_bytes = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = K;
+        q2.out = (uint16_t*)a->out;
+        q2.out_stride = a->out_stride;
+        q2.M = M;
+        q2.K = N;
+        q2.n_tiles = K / 256;
+        q2.addend = (const uint16_t*)a->fused_out;
+        q2.addend_stride = a->fused_out_stride;
+        q2.addend_scale = a->routed_scaling_factor;
+        return launch_gemm_i8_256(MODE_PLAIN, q2, t256, s);
+    }
     // int8 W8A8, decode sizes (M <= 128): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
     // (fp32 ic1), quantise ic1, down as int32 partials, reduce with the scales + fused_out * routed_scaling_factor
     if (i8 && (a->packed & 3) == 3 && !knobs().force_generic && !knobs().no_i8_mid) {

@@ -321,6 +321,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256_kernel(const Bf16GemmPar
                             const float4 b4 = *reinterpret_cast<const float4*>(bias_tab + col);
                             o4[0] += b4.x; o4[1] += b4.y; o4[2] += b4.z; o4[3] += b4.w;
                         }
+                        if (MODE == MODE_PLAIN && p.addend && r < rows) {   // + fused_out * routed_scaling_factor (shared expert)
+                            const uint2 av = *reinterpret_cast<const uint2*>(p.addend + (int64_t)(pos0 + r) * p.addend_stride + ntile * 256 + col);
+                            o4[0] += __uint_as_float(av.x << 16) * p.addend_scale;
+                            o4[1] += __uint_as_float(av.x & 0xffff0000u) * p.addend_scale;
+                            o4[2] += __uint_as_float(av.y << 16) * p.addend_scale;
+                            o4[3] += __uint_as_float(av.y & 0xffff0000u) * p.addend_scale;
+                        }
                         if (MODE == MODE_DOWN) { o4[0] *= tw; o4[1] *= tw; o4[2] *= tw; o4[3] *= tw; }
                         uint2 v;
                         v.x = pack_bf16x2(o4[0], o4[1]);

@@ -360,6 +360,13 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_256_kernel(const I8GemmParams 
                         o4[2] = xs * (float)acc[rt][tt][rg * 4 + 2] * w4.z;
                         o4[3] = xs * (float)acc[rt][tt][rg * 4 + 3] * w4.w;
                         if (MODE == MODE_PLAIN) { o4[0] += b4.x; o4[1] += b4.y; o4[2] += b4.z; o4[3] += b4.w; }
+                        if (MODE == MODE_PLAIN && p.addend && r < rows) {   // + fused_out * routed_scaling_factor (shared expert)
+                            const uint2 av = *reinterpret_cast<const uint2*>(p.addend + (int64_t)(pos0 + r) * p.addend_stride + ntile * 256 + col);
+                            o4[0] += __uint_as_float(av.x << 16) * p.addend_scale;
+                            o4[1] += __uint_as_float(av.x & 0xffff0000u) * p.addend_scale;
+                            o4[2] += __uint_as_float(av.y << 16) * p.addend_scale;
+                            o4[3] += __uint_as_float(av.y & 0xffff0000u) * p.addend_scale;
+                        }
                         if (MODE == MODE_DOWN) { o4[0] *= tw4[tt]; o4[1] *= tw4[tt]; o4[2] *= tw4[tt]; o4[3] *= tw4[tt]; }
                         uint2 v;
                         v.x = pack_bf16x2(o4[0], o4[1]);

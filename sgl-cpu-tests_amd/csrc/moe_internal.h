@@ -119,6 +119,10 @@ struct I8GemmParams {
     int N, ksplit, split_kblocks;
     int32_t* partial_i32;
     int out_type;             // PLAIN: SGLK_OUT_* of `out`
+    // PLAIN on the 256-row kernel: out += addend[row][col] * addend_scale in fp32 before the bf16 rounding (shared expert), or null
+    const uint16_t* addend;
+    int64_t addend_stride;    // elements (multiple of 4)
+    float addend_scale;
 };
 int launch_gemm_i8_256(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 int launch_i8_splitk_reduce(const I8GemmParams& q, hipStream_t stream);   // [ksplit][M][N] int32 partials -> out (scales, bias)
@@ -145,6 +149,10 @@ struct Bf16GemmParams {
     // (row-block stride of the packed weight), workgroup = (m-tile, column tile, range); fp32 partial [range][M][out_cols]
     int ksplit, k_full, out_cols;
     float* partial;
+    // PLAIN without split-K: out += addend[row][col] * addend_scale in fp32 before the bf16 rounding (shared expert), or null
+    const uint16_t* addend;
+    int64_t addend_stride;    // elements (multiple of 4)
+    float addend_scale;
 };
 int launch_gemm_bf16_256(int mode, const Bf16GemmParams& p, int max_mtiles, hipStream_t stream);
 

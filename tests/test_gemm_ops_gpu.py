@@ -141,6 +141,35 @@ def test_shared_expert_bf16_and_int8(ops, case):
     assert ref_pred(g["ref_int8"], res8), name
 
 
+@pytest.mark.parametrize("M", [200, 700, 1100, 1300])
+def test_shared_expert_bf16_and_int8_packed_at_prefill_sizes(ops, knob, M):
+    """Packed bf16 / int8 weights from 192 rows on (bf16: from SGLK_SHARED_MID_MAX, below it the split-K passes) run on the tuned
+    256-row kernels of fused_experts -- grouped form with one expert for gate_up + SiLU*mul, dense form with the fused_out addend for
+    down (the generic engine took 0.71 / 0.66 ms at 2048 x 2048 x 7168).  Same contract (/root/reference/test_shared_experts.py:34-53)
+    against the fp32 / int8 oracle compositions, and within rounding of the generic engine (SGLK_FORCE_GENERIC=1)."""
+    N, K, rsf = 512, 1024, 2.5
+    g = torch.Generator().manual_seed(6100 + M)
+    hs = (torch.randn(M, K, generator=g) / K ** 0.5).bfloat16()
+    fused = (torch.randn(M, K, generator=g) * 0.2).bfloat16()       # MLP and addend of comparable size, |out| ~ 1
+    w1 = torch.randn(2 * N, K, generator=g).bfloat16()
+    w2 = (torch.randn(K, N, generator=g) / N ** 0.5).bfloat16()
+    w1q = torch.randint(-127, 128, (2 * N, K), generator=g, dtype=torch.int8)
+    w2q = torch.randint(-127, 128, (K, N), generator=g, dtype=torch.int8)
+    w1s, w2s = torch.rand(2 * N, generator=g) * 2.7e-2, torch.rand(K, generator=g) * (2.7e-2 / N ** 0.5)
+    d = [t.cuda() for t in (hs, fused, w1, w2, w1q, w2q, w1s, w2s)]
+    p1, p2, q1, q2 = (ops.convert_weight_packed(t) for t in d[2:6])
+    bf = lambda: ops.shared_expert_cpu(d[0], p1, p2, d[1], rsf, False, False, False, None, None, None, None, None, True)
+    i8 = lambda: ops.shared_expert_cpu(d[0], q1, q2, d[1], rsf, False, True, False, d[6], d[7], None, None, None, True)
+    out_b, out_i = bf(), i8()
+    ref_b = moe.shared_expert_f32(hs, w1, w2, fused.float(), rsf)
+    ref_i = moe.shared_expert_int8(hs, w1q, w2q, w1s, w2s, fused, rsf)
+    assert ref_pred(ref_b, out_b) and rel_rms(out_b, ref_b) < 6e-3
+    assert ref_pred(ref_i, out_i) and rel_rms(out_i, ref_i) < 6e-3
+    knob(SGLK_FORCE_GENERIC=1)
+    assert rel_rms(out_b, bf().float().cpu()) < 4e-3
+    assert rel_rms(out_i, i8().float().cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("prepack", [False, True])
 @pytest.mark.parametrize("case", recipes.SHARED_FP8_CASES, ids=lambda c: c[0])
 def test_shared_expert_fp8(ops, case, prepack):

@@ -253,7 +253,7 @@ def bench_shared():
         emit(op="shared_expert_fp8", M=M, N=N, K=K, ms=round(ms, 4), gbps=round(byts / ms / 1e6, 1), tflops=round(flop / ms / 1e9, 2))
     b1 = ops.convert_weight_packed((torch.randn(2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
     b2 = ops.convert_weight_packed((torch.randn(K, N, device="cuda", generator=g) * 0.02).bfloat16())
-    for M in (1, 64, 128):
+    for M in (1, 64, 128, 2048):
         hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
         fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         ms = timed(lambda i: ops.shared_expert_cpu(hs, b1, b2, fo, 2.5, False, False, False, None, None, None, None, None, True), 20)
@@ -263,7 +263,7 @@ def bench_shared():
     i2 = ops.convert_weight_packed(torch.randint(-127, 128, (K, N), device="cuda", generator=g, dtype=torch.int8))
     q1 = torch.rand(2 * N, device="cuda", generator=g) * 1e-3
     q2 = torch.rand(K, device="cuda", generator=g) * 1e-3
-    for M in (1, 64, 128):
+    for M in (1, 64, 128, 2048):
         hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
         fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         ms = timed(lambda i: ops.shared_expert_cpu(hs, i1, i2, fo, 2.5, False, True, False, q1, q2, None, None, None, True), 20)
