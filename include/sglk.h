@@ -239,6 +239,8 @@ typedef struct {
 } sglk_shared_expert_args;
 
 size_t sglk_shared_expert_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype);
+/* ... sized so that row-major weights (packed == 0) at prefill sizes are re-tiled into the workspace and run on the packed paths */
+size_t sglk_shared_expert_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t packed);
 int sglk_shared_expert(const sglk_shared_expert_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

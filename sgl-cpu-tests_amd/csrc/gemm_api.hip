@@ -163,6 +163,22 @@ extern "C" size_t sglk_shared_expert_workspace_bytes(int32_t M, int32_t N, int32
     return plan_dense(M, N, K, true, wtype == SGLK_W_INT8).total;
 }
 
+namespace {
+// Row-major shared-expert weights (the reference's own 12-argument call, /root/reference/test_shared_experts.py:68) at prefill
+// sizes: re-tile both into the workspace (one pass over their bytes) and run the packed paths -- 3-5x over the generic engine.
+bool shared_pack_on_the_fly(int M, int N, int K, int wtype, int packed) {
+    if (packed || M < 1 || knobs().force_generic || knobs().no_pack_on_the_fly) return false;
+    if (wtype == SGLK_W_BF16) return (2 * N) % 32 == 0 && K % 32 == 0 && N % 8 == 0;
+    return (wtype == SGLK_W_FP8_E4M3 || wtype == SGLK_W_INT8) && (2 * N) % 16 == 0 && K % 64 == 0 && N % 64 == 0;
+}
+}  // namespace
+
+extern "C" size_t sglk_shared_expert_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t packed) {
+    if (M < 0 || N <= 0 || K <= 0) return 0;
+    const size_t base = align_up(plan_dense(M, N, K, true, wtype == SGLK_W_INT8).total, 256);
+    return shared_pack_on_the_fly(M, N, K, wtype, packed) ? base + align_up((size_t)3 * N * K * (wtype == SGLK_W_BF16 ? 2 : 1), 256) : base;
+}
+
 namespace sglk {
 // the decode-size fp8 path of shared_expert_impl (two split-K passes of the weight-streaming kernel), the one whose last
 // launch can take the routed experts' combine as a slot addend
@@ -199,6 +215,24 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
     if (M == 0) return SGLK_OK;
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)a->workspace;
+    // row-major weights, prefill-size M, and the caller sized the workspace with _ex: re-tile into the workspace, run as packed
+    if (!moe && shared_pack_on_the_fly(M, N, K, a->wtype, a->packed)) {
+        const size_t base = align_up(w.total, 256), elt = a->wtype == SGLK_W_BF16 ? 2 : 1;
+        if (a->workspace_bytes >= base + (size_t)3 * N * K * elt) {
+            unsigned char* p1 = ws + base;
+            unsigned char* p2 = p1 + (size_t)2 * N * K * elt;
+            rc = sglk_pack_weight(a->w1, p1, 1, 2 * N, K, a->wtype, stream);
+            if (rc != SGLK_OK) return rc;
+            rc = sglk_pack_weight(a->w2, p2, 1, K, N, a->wtype, stream);
+            if (rc != SGLK_OK) return rc;
+            sglk_shared_expert_args b = *a;
+            b.w1 = p1;
+            b.w2 = p2;
+            b.packed = 3;
+            b.workspace_bytes = base;
+            return shared_expert_impl(&b, stream, nullptr);
+        }
+    }
     int4* tile_info = (int4*)(ws + w.tile_info);
     int* num_tiles = (int*)(ws + w.num_tiles);
     uint16_t* ic1 = (uint16_t*)(ws + w.ic1);

@@ -167,6 +167,7 @@ _SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "sglk_shared_expert_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 4),
+    "sglk_shared_expert_workspace_bytes_ex": (ctypes.c_size_t, [ctypes.c_int32] * 5),
     "sglk_shared_expert": (ctypes.c_int, [ctypes.POINTER(SharedExpertArgs), ctypes.c_void_p]),
     "sglk_scaled_mm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int32] * 5),
     "sglk_scaled_mm": (ctypes.c_int, [ctypes.POINTER(ScaledMmArgs), ctypes.c_void_p]),

@@ -465,7 +465,8 @@ def shared_expert_cpu(hidden_states, w1, w2, fused_experts_out, routed_scaling_f
     out = hs if (inplace and hs is hidden_states) else torch.empty_like(hs)
     L = _lib.lib()
     wtype = _WTYPE[wdtype]
-    ws_bytes = L.sglk_shared_expert_workspace_bytes(M, N, K, wtype)
+    pk = _packed_bits(is_vnni, (2 * N, K), (K, N), wdtype)
+    ws_bytes = L.sglk_shared_expert_workspace_bytes_ex(M, N, K, wtype, pk)   # row-major weights at prefill sizes: + re-tiled copies
     ws = _workspace(ws_bytes, hs.device)
     args = _lib.SharedExpertArgs(
         hidden=hs.data_ptr(), hidden_stride=hs.stride(0), out=out.data_ptr(), out_stride=out.stride(0),
@@ -473,7 +474,7 @@ def shared_expert_cpu(hidden_states, w1, w2, fused_experts_out, routed_scaling_f
         w1_scale=w1_scale.data_ptr() if w1_scale is not None else None,
         w2_scale=w2_scale.data_ptr() if w2_scale is not None else None,
         fused_out=fo.data_ptr(), fused_out_stride=fo.stride(0), routed_scaling_factor=float(routed_scaling_factor),
-        M=M, N=N, K=K, wtype=wtype, packed=_packed_bits(is_vnni, (2 * N, K), (K, N), wdtype),
+        M=M, N=N, K=K, wtype=wtype, packed=pk,
         block_n=bn, block_k=bk, workspace=ws.data_ptr(), workspace_bytes=ws_bytes)
     _lib.check(L.sglk_shared_expert(ctypes.byref(args), _stream(hs)), "shared_expert_cpu")
     if inplace and out is not hidden_states:

@@ -165,6 +165,11 @@ def test_shared_expert_bf16_and_int8_packed_at_prefill_sizes(ops, knob, M):
     ref_i = moe.shared_expert_int8(hs, w1q, w2q, w1s, w2s, fused, rsf)
     assert ref_pred(ref_b, out_b) and rel_rms(out_b, ref_b) < 6e-3
     assert ref_pred(ref_i, out_i) and rel_rms(out_i, ref_i) < 6e-3
+    # row-major weights (the reference's own 12-argument call passes is_vnni=False, test_shared_experts.py:68): re-tiled into the
+    # workspace at these sizes, then the very same kernels -> the same bits
+    rm_b = ops.shared_expert_cpu(d[0], d[2], d[3], d[1], rsf, False, False, False, None, None, None, False)
+    rm_i = ops.shared_expert_cpu(d[0], d[4], d[5], d[1], rsf, False, True, False, d[6], d[7], None, False)
+    assert torch.equal(rm_b, out_b) and torch.equal(rm_i, out_i)
     knob(SGLK_FORCE_GENERIC=1)
     assert rel_rms(out_b, bf().float().cpu()) < 4e-3
     assert rel_rms(out_i, i8().float().cpu()) < 4e-3
@@ -202,6 +207,9 @@ def test_shared_expert_fp8_between_decode_and_prefill_sizes(ops, knob, M):
     ref = moe.shared_expert_f32(inp["a"].cpu(), W1, W2, inp["fused"].cpu().float(), rsf)
     assert ref_pred(ref, out)
     assert rel_rms(out, ref) < 6e-3
+    rowmajor = ops.shared_expert_cpu(inp["a"], inp["w1"], inp["w2"], inp["fused"], rsf, False, False, True, inp["w1s"], inp["w2s"],
+                                     [bn, bk], None, None, False)
+    assert torch.equal(rowmajor, out), "row-major weights are re-tiled into the workspace and take the packed path"
     knob(SGLK_SHARED_MID_MAX=192)
     tile = call()
     assert rel_rms(out, tile.float().cpu()) < 4e-3

@@ -11,10 +11,12 @@ import sgl_kernel  # noqa: F401,E402
 ops = torch.ops.sgl_kernel
 g = torch.Generator(device="cuda").manual_seed(9)
 N, K = 2048, 7168
-b1 = ops.convert_weight_packed((torch.randn(2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
-b2 = ops.convert_weight_packed((torch.randn(K, N, device="cuda", generator=g) * 0.02).bfloat16())
-i1 = ops.convert_weight_packed(torch.randint(-127, 128, (2 * N, K), device="cuda", generator=g, dtype=torch.int8))
-i2 = ops.convert_weight_packed(torch.randint(-127, 128, (K, N), device="cuda", generator=g, dtype=torch.int8))
+PACKED = os.environ.get("ROWMAJOR", "0") != "1"      # ROWMAJOR=1: the weights as the reference's 12-argument call passes them
+pack = ops.convert_weight_packed if PACKED else (lambda t: t)
+b1 = pack((torch.randn(2 * N, K, device="cuda", generator=g) * 0.02).bfloat16())
+b2 = pack((torch.randn(K, N, device="cuda", generator=g) * 0.02).bfloat16())
+i1 = pack(torch.randint(-127, 128, (2 * N, K), device="cuda", generator=g, dtype=torch.int8))
+i2 = pack(torch.randint(-127, 128, (K, N), device="cuda", generator=g, dtype=torch.int8))
 q1 = torch.rand(2 * N, device="cuda", generator=g) * 1e-3
 q2 = torch.rand(K, device="cuda", generator=g) * 1e-3
 
@@ -35,6 +37,6 @@ def timed(fn):
 for M in [int(x) for x in sys.argv[1:]]:
     hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
     fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    tb = timed(lambda: ops.shared_expert_cpu(hs, b1, b2, fo, 2.5, False, False, False, None, None, None, None, None, True))
-    ti = timed(lambda: ops.shared_expert_cpu(hs, i1, i2, fo, 2.5, False, True, False, q1, q2, None, None, None, True))
-    print(json.dumps({"M": M, "bf16_ms": round(tb, 4), "int8_ms": round(ti, 4)}), flush=True)
+    tb = timed(lambda: ops.shared_expert_cpu(hs, b1, b2, fo, 2.5, False, False, False, None, None, None, None, None, PACKED))
+    ti = timed(lambda: ops.shared_expert_cpu(hs, i1, i2, fo, 2.5, False, True, False, q1, q2, None, None, None, PACKED))
+    print(json.dumps({"M": M, "bf16_ms": round(tb, 4), "int8_ms": round(ti, 4), "packed": PACKED}), flush=True)
