@@ -74,6 +74,35 @@ __global__ __launch_bounds__(256) void pack_bf16_vnni2_kernel(const unsigned* __
     }
 }
 
+// bf16 pack, cols % 64 == 0: one workgroup per tile of 32 rows x 32 (k, k+1) pairs.  The row-major side is read in whole 128-byte
+// row segments (one uint4 per thread), transposed through LDS ([pair][row], padded), and the packed side -- 4 KiB contiguous per
+// tile -- is written as one uint4 per thread.  The pair-per-thread kernel above reads 4 bytes from 32 different rows per wave
+// instruction and moved 2 TB/s; the re-tiling in front of row-major bf16 GEMMs / shared experts is exactly this pass.
+__global__ __launch_bounds__(256) void pack_bf16_vnni2_tiled_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst,
+                                                                    int64_t rows, int64_t cols, int64_t tiles) {
+    __shared__ unsigned t[32][33];
+    const int64_t kp_n = cols / 2, kt_n = kp_n / 32, per_mat = rows * kp_n;
+    const int tid = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t kt = tile % kt_n, nb = (tile / kt_n) % (rows / 32), b = tile / (kt_n * (rows / 32));
+        {
+            const int row = tid >> 3, c = tid & 7;     // 16-byte chunk c of the row's 128-byte segment = pairs 4c .. 4c+3
+            const uint4 v = *reinterpret_cast<const uint4*>(src + b * per_mat + (nb * 32 + row) * kp_n + kt * 32 + c * 4);
+            t[c * 4 + 0][row] = v.x;
+            t[c * 4 + 1][row] = v.y;
+            t[c * 4 + 2][row] = v.z;
+            t[c * 4 + 3][row] = v.w;
+        }
+        __syncthreads();
+        {
+            const int kp = tid >> 3, r4 = (tid & 7) * 4;   // packed order: [pair][row], four rows per thread
+            const uint4 v = make_uint4(t[kp][r4], t[kp][r4 + 1], t[kp][r4 + 2], t[kp][r4 + 3]);
+            *reinterpret_cast<uint4*>(dst + b * per_mat + (nb * kp_n + kt * 32) * 32 + tid * 4) = v;
+        }
+        __syncthreads();
+    }
+}
+
 static int pack_common(const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int wtype,
                        void* stream, bool unpack) {
     SGLK_REQUIRE(src && dst, SGLK_ERR_INVALID, "pack_weight: null pointer");
@@ -94,7 +123,11 @@ static int pack_common(const void* src, void* dst, int64_t batch, int64_t rows, 
         if (unpack)
             hipLaunchKernelGGL(pack_bf16_vnni2_kernel<true>, dim3((unsigned)nb), dim3(threads), 0, s, (const unsigned*)src,
                                (unsigned*)dst, rows, cols, pairs);
-        else
+        else if (cols % 64 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+            const int64_t tiles = pairs / 1024;
+            hipLaunchKernelGGL(pack_bf16_vnni2_tiled_kernel, dim3((unsigned)(tiles < 256 * 64 ? tiles : 256 * 64)), dim3(256), 0, s,
+                               (const unsigned*)src, (unsigned*)dst, rows, cols, tiles);
+        } else
             hipLaunchKernelGGL(pack_bf16_vnni2_kernel<false>, dim3((unsigned)nb), dim3(threads), 0, s, (const unsigned*)src,
                                (unsigned*)dst, rows, cols, pairs);
         SGLK_CHECK_LAUNCH("pack_weight");
