@@ -32,7 +32,7 @@ void read_env() {
     Knobs k;
     k.moe_tile_m = env_int("SGLK_MOE_TILE_M", 0);
     k.mid_lo = env_int("SGLK_MID_LO", 8);
-    k.mid_hi = env_int("SGLK_MID_HI", 160);
+    k.mid_hi = env_int("SGLK_MID_HI", 0);
     k.dense_mid_max = env_int("SGLK_DENSE_MID_MAX", 1024);
     k.shared_mid_max = env_int("SGLK_SHARED_MID_MAX", 1024);
     k.no_tuned_splitk = env_set("SGLK_NO_TUNED_SPLITK");

@@ -14,7 +14,7 @@ struct Knobs {
     int shared_mid_max = 1024;   // SGLK_SHARED_MID_MAX: fp8 shared expert below this M runs as split-K passes of the weight-streaming kernel
     int dense_mid_max = 1024;    // SGLK_DENSE_MID_MAX: dense GEMMs below this M may take the weight-streaming kernels when the 256-row kernel would have few workgroups (192 = round-1 policy)
     int mid_i8_hi = 44, mid_bf16_hi = 44;   // SGLK_MID_I8_HI / SGLK_MID_BF16_HI: rows per expert below which int8 / bf16 experts take their weight-streaming kernels
-    int mid_lo = 8, mid_hi = 160; // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256
+    int mid_lo = 8, mid_hi = 0;   // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256; mid_hi 0 = by the experts' size (pick_tile_m)
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
     bool no_i8_mid = false;      // SGLK_NO_I8_MID
     bool no_bf16_mid = false;    // SGLK_NO_BF16_MID
