@@ -1,5 +1,5 @@
-"""Randomised parity sweep of the fp8 (W8A16) fused_experts paths against the plain-C oracle (test infrastructure, not a
-benchmark): random shapes, expert counts, routing (incl. -1 ids and skewed loads), block sizes, packed / row-major weights,
+"""Randomised parity sweep of the fp8 (W8A16) fused_experts paths against the plain-C oracle, and (FUZZ_KIND=int8 | bf16) of the int8
+W8A8 / bf16 paths against oracle/moe.py (test infrastructure, not a benchmark): random shapes, expert counts, routing (incl. -1 ids and skewed loads), block sizes, packed / row-major weights,
 in-place or not.  Every kernel choice of the library (stream / mid / 128 / 256-row, generic engine) is hit by shape alone.
 usage: python tools/fuzz_moe.py [iterations] [seed]      -> one line per failure, a summary line at the end"""
 import os
@@ -15,10 +15,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import sgl_kernel  # noqa: F401,E402
 from sgl_kernel import _lib, _ops  # noqa: E402
 import recipes  # noqa: E402
-from oracle import c_oracle  # noqa: E402
+from oracle import c_oracle, moe  # noqa: E402
 
 ops = torch.ops.sgl_kernel
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+KIND = os.environ.get("FUZZ_KIND", "fp8")
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 fails, paths = 0, {}
 
@@ -49,6 +50,39 @@ for it in range(iters):
     packed = rng.random() < 0.8
     inplace = rng.random() < 0.5
     g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    if KIND != "fp8":
+        # ---- int8 W8A8 (/root/reference/test_moe_int8.py:97-137: mean relative error < 1 %) and bf16 (test_moe.py:96-107) ----------
+        E = min(E, 16)          # the torch oracle walks the experts
+        topk = min(topk, E)
+        tw, ids = routing(M, E, topk, kind, g)
+        if KIND == "int8":
+            inp = recipes.moe_int8_inputs(M, N, K, E, topk, rng.randrange(1 << 30))
+            ref = moe.fused_experts_int8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], tw, ids).float()
+            scales = (inp["w1s"].cuda(), inp["w2s"].cuda())
+        else:
+            inp = recipes.moe_bf16_inputs(M, N, K, E, topk, rng.randrange(1 << 30))
+            ref = moe.fused_experts_f32(inp["a"], inp["w1"].float(), inp["w2"].float(), tw, ids)
+            scales = (None, None)
+        k = 2.0 / max(float(ref.abs().max()), 1e-6)
+        tw, ref = tw * k, ref * k
+        w1d, w2d = inp["w1"].cuda(), inp["w2"].cuda()
+        if packed:
+            w1d, w2d = ops.convert_weight_packed(w1d), ops.convert_weight_packed(w2d)
+        out = ops.fused_experts_cpu(inp["a"].cuda(), w1d, w2d, tw.cuda(), ids.cuda(), inplace, KIND == "int8", False, scales[0], scales[1],
+                                    None, None, None, packed)
+        torch.cuda.synchronize()
+        o = out.float().cpu()
+        ok_pred = torch.allclose(ref.bfloat16(), out.cpu(), rtol=1e-2, atol=1e-2)
+        rel = float((o - ref).norm() / ref.norm().clamp_min(1e-12))
+        mre = float((o - ref).abs().mean() / ref.abs().mean().clamp_min(1e-12))
+        path = _ops.last_path & _lib.PATH_TILE_MASK
+        paths[path] = paths.get(path, 0) + 1
+        bad = (not ok_pred or mre > 0.01) if KIND == "int8" else (not ok_pred or rel > 6e-3)
+        if bad or not torch.isfinite(o).all():
+            fails += 1
+            print(f"FAIL {KIND} it={it} M={M} N={N} K={K} E={E} topk={topk} {kind} packed={packed} inplace={inplace} path={_ops.last_path:#x} "
+                  f"rel={rel:.2e} mre={mre:.2e} pred={ok_pred}", flush=True)
+        continue
     a = (torch.randn(M, K, generator=g) / K ** 0.5).bfloat16()
     w1, w2 = recipes.fp8_weight((E, 2 * N, K), g), recipes.fp8_weight((E, K, N), g)
     w1s = torch.randn(E, 2 * N // bn, K // 128, generator=g) * recipes.SCALE_FACTOR
@@ -75,5 +109,5 @@ for it in range(iters):
         print(f"FAIL it={it} M={M} N={N} K={K} E={E} topk={topk} bn={bn} {kind} packed={packed} inplace={inplace} "
               f"path={_ops.last_path:#x} rel={rel:.2e} pred={ok_pred} bad={int(bad.sum())}/{bad.numel()} max|diff|={float(diff.max()):.4f} "
               f"max|ref|={float(ref.abs().max()):.2f} max|tw|={float(tw.abs().max()):.2f}", flush=True)
-print(f"fuzz_moe fp8: {iters} cases, {fails} failures, tile paths {dict(sorted(paths.items()))}")
+print(f"fuzz_moe {KIND}: {iters} cases, {fails} failures, tile paths {dict(sorted(paths.items()))}")
 sys.exit(1 if fails else 0)
