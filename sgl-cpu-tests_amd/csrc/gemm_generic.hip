@@ -371,12 +371,14 @@ int launch_splitk_reduce_silu_mul(const float* partial, int ksplit, int rows, in
 // Split-K plan: small-M dense GEMMs put only ceil(M/64) * ceil(N/64) workgroups on 256 CUs and each walks the whole
 // reduction with one synchronous load per stage; cutting K lifts the number of workgroups to ~512.  Ranges are whole
 // pairs of 64-deep stages (fp8 K blocks) and at least four stages long; the fp32 partials are bounded to 64 MiB.
+// (Round 1 stopped at 256 rows; tall narrow outputs -- 2048 x 320 x 7168, the 576-wide kv_a projection of MLA at prefill sizes -- have
+// as few tiles as a decode batch and took 0.1-0.2 ms with one workgroup walking 112 stages: any M now, bounded by the tile count.)
 int generic_ksplit(int M, int N, int K) {
-    if (M <= 0 || M > 256) return 1;
+    if (M <= 0) return 1;
     const int64_t tiles = ceil_div(M, kGenericTileM) * ceil_div(N, 64);
     const int stages = (int)ceil_div(K, 64);
-    if (tiles >= 256 || stages < 8) return 1;
-    int ks = (int)(512 / tiles);
+    if (tiles >= (M > 256 ? 600 : 256) || stages < 8) return 1;
+    int ks = (int)((M > 256 ? 1024 : 512) / tiles);
     if (ks > stages / 4) ks = stages / 4;
     if (ks > 32) ks = 32;
     while (ks > 1 && (int64_t)ks * M * N * 4 > (64ll << 20)) --ks;

@@ -23,6 +23,29 @@ fails = 0
 count = {"fp8": 0, "int8": 0, "bf16": 0}
 
 
+TIMES = os.environ.get("FUZZ_TIME", "0") == "1"     # FUZZ_TIME=1: also time every case and list the ones furthest below their roofline
+slow = []
+
+
+def rate(kind, desc, fn, M, N, K):
+    if not TIMES:
+        return
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    wb = N * K * (2 if kind == "bf16" else 1)
+    t_min = max(2.0 * M * N * K / (5.0e15 if kind == "int8" else 2.5e15), (wb + 2.0 * M * (N + K)) / 8e12) * 1e3
+    if t_min > 3e-3:      # problems below ~3 us of roofline time are bound by launch + host latency (~20 us per eager call)
+        slow.append((t_min / ms, ms, kind, desc))
+
+
 def check(kind, desc, out, ref, rms_tol):
     global fails
     o = out.float().cpu()
@@ -55,6 +78,8 @@ for it in range(iters):
         out = ops.fp8_scaled_mm_cpu(inp["data"].cuda(), w, inp["scales"].cuda(), [bn, 128], inp["bias"].cuda() if has_bias else None,
                                     torch.bfloat16, packed)
         check(kind, desc + f" bn={bn}", out, ref, 4e-3)
+        xd, sd, bd = inp["data"].cuda(), inp["scales"].cuda(), inp["bias"].cuda() if has_bias else None
+        rate(kind, desc, lambda: ops.fp8_scaled_mm_cpu(xd, w, sd, [bn, 128], bd, torch.bfloat16, packed), M, N, K)
     elif kind == "int8":
         inp = recipes.gemm_int8_inputs(M, N, K, has_bias, seed)
         xq, xs = ogemm.per_token_quant_int8(inp["A"])
@@ -64,6 +89,8 @@ for it in range(iters):
         out = ops.int8_scaled_mm_with_quant(inp["A"].cuda(), w, inp["Bs"].cuda(), inp["bias"].cuda() if has_bias else None, torch.bfloat16,
                                             packed)
         check(kind, desc, out, ref, 4e-3)
+        xd, sd, bd = inp["A"].cuda(), inp["Bs"].cuda(), inp["bias"].cuda() if has_bias else None
+        rate(kind, desc, lambda: ops.int8_scaled_mm_with_quant(xd, w, sd, bd, torch.bfloat16, packed), M, N, K)
     else:
         inp = recipes.gemm_bf16_inputs(M, N, K, has_bias, seed)
         ref = ogemm.linear_bf16(inp["mat1"], inp["mat2"], inp.get("bias"))
@@ -71,6 +98,10 @@ for it in range(iters):
         w = ops.convert_weight_packed(w) if packed else w
         out = ops.weight_packed_linear(inp["mat1"].cuda(), w, inp["bias"].cuda() if has_bias else None, packed)
         check(kind, desc, out, ref, 4e-3)
+        xd, bd = inp["mat1"].cuda(), inp["bias"].cuda() if has_bias else None
+        rate(kind, desc, lambda: ops.weight_packed_linear(xd, w, bd, packed), M, N, K)
     torch.cuda.synchronize()
+for frac, ms, kind, desc in sorted(slow)[:25]:
+    print(f"  slow: {frac:.3f} of its roofline, {ms:.4f} ms  {kind} {desc}")
 print(f"fuzz_gemm: {count} cases, {fails} failures")
 sys.exit(1 if fails else 0)
