@@ -22,6 +22,8 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 KIND = os.environ.get("FUZZ_KIND", "fp8")
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 fails, paths = 0, {}
+TIMES = os.environ.get("FUZZ_TIME", "0") == "1"
+slow = []
 
 
 def routing(M, E, topk, kind, g):
@@ -102,6 +104,23 @@ for it in range(iters):
     rel = float((o - ref).norm() / ref.norm().clamp_min(1e-12))
     path = _ops.last_path & _lib.PATH_TILE_MASK
     paths[path] = paths.get(path, 0) + 1
+    if TIMES:      # FUZZ_TIME=1: time the case, keep its distance from max(flops / 2.5 PF, touched weight bytes / 8 TB/s)
+        fn = lambda: ops.fused_experts_cpu(d[0], w1d, w2d, d[3], d[4], False, False, True, d[5], d[6], [bn, 128], None, None, packed)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        valid = ids[(ids >= 0) & (ids < E)]
+        touched = int(torch.unique(valid).numel())
+        t_min = max(6.0 * valid.numel() * N * K / 2.5e15, touched * 3.0 * N * K / 8e12) * 1e3
+        if t_min > 3e-3:
+            slow.append((t_min / ms, ms, f"M={M} N={N} K={K} E={E} topk={topk} bn={bn} {kind} packed={packed} path={path} rows/expert={valid.numel() / max(touched, 1):.0f}"))
     if not ok_pred or rel > 6e-3 or not torch.isfinite(o).all():
         fails += 1
         diff = (o - ref.bfloat16().float()).abs()
@@ -109,5 +128,7 @@ for it in range(iters):
         print(f"FAIL it={it} M={M} N={N} K={K} E={E} topk={topk} bn={bn} {kind} packed={packed} inplace={inplace} "
               f"path={_ops.last_path:#x} rel={rel:.2e} pred={ok_pred} bad={int(bad.sum())}/{bad.numel()} max|diff|={float(diff.max()):.4f} "
               f"max|ref|={float(ref.abs().max()):.2f} max|tw|={float(tw.abs().max()):.2f}", flush=True)
+for frac, ms, desc in sorted(slow)[:20]:
+    print(f"  slow: {frac:.3f} of its roofline, {ms:.4f} ms  {desc}")
 print(f"fuzz_moe {KIND}: {iters} cases, {fails} failures, tile paths {dict(sorted(paths.items()))}")
 sys.exit(1 if fails else 0)
