@@ -21,6 +21,26 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 fails = 0
 unsupported = set()
+TIMES = os.environ.get("FUZZ_TIME", "0") == "1"     # also time every case against max(flops / 2.5 PF, KV bytes / 8 TB/s)
+slow = []
+
+
+def rate(desc, fn, flops, byts):
+    if not TIMES:
+        return
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    t_min = max(flops / 2.5e15, byts / 8e12) * 1e3
+    if t_min > 2e-3:
+        slow.append((t_min / ms, ms, desc))
 
 
 def report(kind, desc, o, ref):
@@ -64,6 +84,11 @@ for it in range(iters):
                                      inp["b_seq_len"], inp["b_prefix"], inp["b_extend"], 1.0 / D ** 0.5, logit_cap=cap)
         report("extend", f"it={it} B={B} ctx={N_CTX} HQ={HQ} HKV={HKV} D={D} DV={DV} mla={mla} cap={cap} i64={i64} seed={seed} "
                f"ext={inp['b_extend'].tolist()} prefix={inp['b_prefix'].tolist()}", o, ref)
+        fl = sum(2.0 * HQ * int(e) * (int(p) + (int(e) + 1) / 2.0) * (D + DV) for e, p in zip(inp["b_extend"], inp["b_prefix"]))
+        rate(f"extend B={B} ctx={N_CTX} HQ={HQ} HKV={HKV} D={D} DV={DV} mla={mla} ext={inp['b_extend'].tolist()} prefix={inp['b_prefix'].tolist()}",
+             lambda: ops.extend_attention_cpu(d["q_extend"], d["k_extend"], d["v_extend"], o, d["k_buffer"], d["v_buffer"], rtt, ridx,
+                                              d["b_seq_len"], d["b_extend"], d["b_start_loc_extend"], int(inp["b_extend"].max()),
+                                              1.0 / D ** 0.5, cap), fl, 0.0)
     else:
         # ---- decode ----------------------------------------------------------------------------------------------------------
         n_dec += 1
@@ -90,5 +115,11 @@ for it in range(iters):
                                      inp["b_req_idx"], inp["b_seq_len"], 1.0 / D ** 0.5, logit_cap=cap)
         ref = ref[0] if isinstance(ref, tuple) else ref
         report("decode", f"it={it} B={B} S={S} HQ={HQ} HKV={HKV} D={D} DV={DV} alias={alias} cap={cap} seed={seed}", o, ref)
+        qd, locd, rttd, rid, sld = inp["q"].cuda(), inp["loc"].cuda(), inp["req_to_token"].cuda(), inp["b_req_idx"].cuda(), inp["b_seq_len"].cuda()
+        rate(f"decode B={B} S={S} HQ={HQ} HKV={HKV} D={D} DV={DV} alias={alias}",
+             lambda: ops.decode_attention_cpu(qd, kb, vb, o, key, value, locd, logits, rttd, rid, sld, 1.0 / D ** 0.5, cap),
+             2.0 * B * HQ * S * (D + DV), 2.0 * B * S * HKV * (D if alias else D + DV))
+for frac, ms, desc in sorted(slow)[:22]:
+    print(f"  slow: {frac:.3f} of its roofline, {ms:.4f} ms  {desc}")
 print(f"fuzz_attn: {n_ext} extend + {n_dec} decode cases, {fails} failures; refused head sizes: {sorted(unsupported)}")
 sys.exit(1 if fails else 0)
