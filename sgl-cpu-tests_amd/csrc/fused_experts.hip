@@ -52,10 +52,12 @@ int pick_tile_m(int M, int N, int K, int E, int topk, int block_n, int64_t hidde
         if (f == 128) return 128;
     }
     // crossovers in average rows per expert (A/B overrides SGLK_MID_LO / SGLK_MID_HI).  mid -> 256: above 96 rows an expert needs
-    // two mid tiles and streams its weights twice; at Qwen3's 4.7 MB per expert that is a wash up to ~160 rows, for larger experts
-    // the 256-row kernel wins from ~72 rows on (tools/ab_moe_shapes.py, profiles/r02_ab_moe_shapes.txt: N = 384, K = 7168, E = 256 at
-    // 123 rows per expert -- the reference bench's own shape, bench_moe.py:144-145 -- 1.14 -> 0.94 ms)
-    const int64_t lo = kn.mid_lo, hi = kn.mid_hi > 0 ? kn.mid_hi : ((int64_t)3 * N * K > (6ll << 20) ? 72 : 160);
+    // two mid tiles and streams its weights twice; at Qwen3's shape (N = 768, K = 2048) and at DeepSeek-like experts (N = 2048,
+    // K = 7168) that is a wash or a small win up to ~160 rows.  Narrow experts behind a deep reduction are different: the mid
+    // kernel's DOWN stage is thousands of workgroups with a three-block reduction each, and the 256-row kernel wins from ~72 rows on
+    // (tools/ab_moe_shapes.py, profiles/r02_ab_moe_shapes.txt: N = 384, K = 7168, E = 256 at 123 rows per expert -- the reference
+    // bench's own shape, bench_moe.py:144-145 -- 1.14 -> 0.94 ms)
+    const int64_t lo = kn.mid_lo, hi = kn.mid_hi > 0 ? kn.mid_hi : ((N <= 512 && K >= 4096) ? 72 : 160);
     if (ok_stream && S < lo * E) return kStreamTileM;
     if (ok_mid && S < hi * E) return kMidTileM;
     if (ok_stream && !ok_mid && S < (int64_t)44 * E) return kStreamTileM;
