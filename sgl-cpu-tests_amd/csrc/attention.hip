@@ -1377,6 +1377,11 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
         else if (knobs().dec_splits == 0 && a->D >= 256 && per_split * eff > cus) {   // narrow heads: several workgroups share a CU
             eff = (int)(cus / per_split);
             if (eff < 1) eff = 1;
+        } else if (knobs().dec_splits == 0 && a->D < 256 && per_split * eff > (int64_t)8 * cus) {
+            // narrow heads with many (request, kv head) pairs: beyond ~8 workgroups per CU more splits only add prologues (page
+            // lookups, first tile) -- 40 requests x 22 MHA heads x 8 splits of a 33-key sequence were 7040 workgroups and 52 us
+            eff = (int)((int64_t)8 * cus / per_split);
+            if (eff < 1) eff = 1;
         }
     }
     p.splits = eff;
