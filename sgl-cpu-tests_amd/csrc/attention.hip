@@ -1174,6 +1174,17 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
     __shared__ float wsum_s;
     const int b = blockIdx.x, h = blockIdx.y;
     const float* src = logits + ((int64_t)b * HQ + h) * logit_splits * (DV + 1);
+    // the partial rows do not depend on the weights: the first eight splits' values of this thread's (at most two, DV <= 512)
+    // columns are requested BEFORE the barrier, so the lse round trip and the partials' round trip overlap instead of following each
+    // other (a split that holds no key has lse = -inf and possibly stale numbers in its row: selected away, never multiplied)
+    constexpr int kPre = 8;
+    float pre[2][kPre];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = threadIdx.x + it * 256;
+#pragma unroll
+        for (int s = 0; s < kPre; ++s) pre[it][s] = (c < DV && s < splits) ? src[s * (DV + 1) + c] : 0.f;
+    }
     if (threadIdx.x < 64) {
         const int s = threadIdx.x;
         const float lse = s < splits ? src[s * (DV + 1) + DV] : -INFINITY;
@@ -1189,7 +1200,23 @@ __global__ __launch_bounds__(256) void decode_merge_kernel(const float* __restri
     }
     __syncthreads();
     const float wsum = wsum_s;
-    for (int c = threadIdx.x; c < DV; c += 256) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = threadIdx.x + it * 256;
+        if (c >= DV) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < kPre; ++s) {
+            const float w = s < splits ? wgt[s] : 0.f;
+            if (w != 0.f) acc += w * pre[it][s];
+        }
+        for (int s = kPre; s < splits; ++s) {
+            const float w = wgt[s];
+            if (w != 0.f) acc += w * src[s * (DV + 1) + c];
+        }
+        o[(int64_t)b * o_s0 + (int64_t)h * o_s1 + c] = f32_to_bf16_bits(wsum > 0.f ? acc / wsum : 0.f);
+    }
+    for (int c = threadIdx.x + 512; c < DV; c += 256) {   // wider value heads than any built today: the plain walk
         float acc = 0.f;
         for (int s = 0; s < splits; ++s) {
             const float w = wgt[s];
