@@ -13,6 +13,7 @@ using namespace sglk;
 namespace {
 
 constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
+constexpr bool kS128Default = false;    // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
 
 struct StageTimer {
     int max_calls = 0, calls = 0;
@@ -269,7 +270,13 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     const bool tuned_i8 = !mid_i8 && tuned_int8_ok(a);
     const bool mid_b16 = mid_bf16_ok(a);
     const bool tuned_b16 = !mid_b16 && tuned_bf16_ok(a);
-    const int tile_m = a8 ? 256 : tuned ? pick_tile_m(M, N, K, E, topk, a->block_n, a->hidden_stride) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
+    int tile_m = a8 ? 256 : tuned ? pick_tile_m(M, N, K, E, topk, a->block_n, a->hidden_stride) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
+    // the 256-row regime on 128-token tiles, four waves, two workgroups per CU (moe_gemm_fp8w_s128.hip): the two-term split
+    // whose prologue / epilogue hide behind the co-resident workgroup's main loop
+    const bool s128 = tuned && !a8 && tile_m == 256 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (int64_t)M * K * 2 < (1ll << 32) &&
+                      (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().s128 >= 0 ? knobs().s128 == 1 : kS128Default) &&
+                      knobs().split != 0;
+    if (s128) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -317,8 +324,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 
     // 256-row regime: the two-term e4m3 split on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip) instead of the
     // bf16-MFMA kernel -- the same W8A16 contract (SGLK_SPLIT=0 / 1 overrides)
-    const bool split = tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
-                       (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault);
+    const bool split = s128 || (tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
+                                (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault));
     if (split) {
         uint8_t* xq = ws + w.xq;
         uint8_t* xs = ws + w.xs;
@@ -409,7 +416,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
-        rc = launch_moe_gemm_fp8w_split(MODE_GATE_UP, q1, max_tiles, s);
+        rc = s128 ? launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s) : launch_moe_gemm_fp8w_split(MODE_GATE_UP, q1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
         A8GemmParams q2{};
@@ -436,7 +443,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
 #endif
-        rc = launch_moe_gemm_fp8w_split(MODE_DOWN, q2, max_tiles, s);
+        rc = s128 ? launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s) : launch_moe_gemm_fp8w_split(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream join failed");
         mark(3);

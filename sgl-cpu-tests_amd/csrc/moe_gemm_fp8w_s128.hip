@@ -1,0 +1,538 @@
+// Large-M grouped W8A16 GEMM of fused_experts, two-term e4m3 split on the block-scaled fp8 matrix cores, 128-token tiles,
+// TWO workgroups per CU.  Same operator contract, oracle and data formats as moe_gemm_fp8w_split.hip
+// (/root/reference/test_moe_fp8_ext.py:22-25,70-91; /root/reference/bench_moe.py:113-130): x = hi + lo exactly, both terms e4m3
+// under one power-of-two scale per (row, 128-wide block); rows are [hi 64 | lo 64] per 64-wide k group in the packed weight
+// tile's k order.
+//
+// Why another tiling.  The 256 x 256 / 8-wave split kernel runs its main loop at 91 % of the matrix pipe but a tile also
+// spends 3.6 us in its prologue (tile table -> row ids -> first operands: dependent round trips) and 7.2 us in its epilogue
+// (SiLU, the split of ic1, stores), with the pipe idle: one workgroup owns the whole CU.  Here a workgroup is FOUR waves (one
+// per SIMD) with a tile of 128 tokens x 256 weight rows, and a CU holds TWO of them (2 x 71 KiB of LDS, 2 x 256 registers
+// per SIMD lane): while one is in its prologue or epilogue the other has the matrix pipe to itself, and a 64-cycle
+// v_mfma_scale_f32_32x32x64_f8f6f4 leaves one wave alone enough issue slots to keep the pipe full.
+//   * waves 4 (weight rows) x 1: a wave owns 64 weight rows (GATE_UP: 32 gate + the 32 matching up rows) for ALL 128 tokens
+//     = 2 x 4 accumulator tiles of 32 x 32 (128 registers), 16 MFMAs per 64-deep stage (hi and lo term);
+//   * weights never touch LDS: no two waves share a weight row, so a wave's A fragments of a stage are four
+//     buffer_load_dwordx4 straight from the packed tiles (pack.hip; a lane's 2 x 16 bytes are its operand bytes), issued THREE
+//     stages ahead into a rotation of four register sets;
+//   * activations go through a ring of four 16-KiB LDS buffers filled by LDS-DMA (rows gathered through sorted_slot by the
+//     per-lane source address), three stages ahead; one counted s_waitcnt + one barrier per stage.  Three stages = 96 KiB in
+//     flight per workgroup: a workgroup that has the CU to itself runs its stages twice as fast, and with two stages in flight
+//     (first version) it was bound by memory latency at 49 % of the pipe;
+//   * half the tile height of the 256-row kernels: an expert's last tile wastes at most 127 rows instead of 255.
+#include "fp8_split.h"
+#include "knobs.h"
+#include "moe_internal.h"
+
+namespace sglk {
+
+typedef __attribute__((address_space(3))) void* lptr_s1_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+namespace gs128 {
+
+constexpr int kBM = 128;
+constexpr int kStageX = kBM * 128;            // 16 KiB: 128 tokens x (hi 64 + lo 64) bytes
+constexpr int kRing = 4;
+constexpr int kMaxKB = 32;                    // reduction length <= 4096
+constexpr int kImage = 64 * 1024;             // the ring (4 x 16 KiB) = the DOWN epilogue image (128 rows x 512 B)
+constexpr int kScaleOff = kImage;                         // sc[16 pieces][kMaxKB] f32 (2 KiB)
+constexpr int kXsOff = kScaleOff + 16 * kMaxKB * 4;       // xs[kb][128 tokens] E8M0 bytes (4 KiB)
+constexpr int kRowTabOff = kXsOff + kMaxKB * kBM;         // DOWN: output slot + routing weight per tile row (1 KiB)
+constexpr int kLds = kRowTabOff + 2 * kBM * 4;            // 71 KiB: two workgroups per CU
+constexpr int kAmaxOff = 48 * 1024;                       // GATE_UP epilogue (ring dead): amax[4 waves][128] f32, above the 32-KiB image
+
+// s_waitcnt immediate (gfx9 encoding): vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
+constexpr int wc(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+SGLK_DEV float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// weight block scale s = mant * 2^(eb - 127): eb = the E8M0 byte for the MFMA, mant in +-[1,2).  Zero / denormal scales:
+// eb = 0 (2^-127: the block contributes < 1e-30 instead of exactly 0), mant = 1; inf / nan: eb = 127, mant = s (poisons)
+SGLK_DEV void split_scale(float s_in, int& eb, float& mant) {
+    const float s = uniform_f32(s_in);
+    const unsigned u = __float_as_uint(s);
+    const unsigned ex = (u >> 23) & 0xffu;
+    const bool tiny = ex == 0u, special = ex == 0xffu;
+    eb = tiny ? 0 : (special ? 127 : (int)ex);
+    mant = tiny ? 1.f : (special ? s : __uint_as_float((u & 0x807fffffu) | 0x3f800000u));
+}
+
+enum { KB_STEADY = 0, KB_PENULT = 1, KB_LAST = 2 };
+
+// ODD = kblocks & 1: stage t multiplies with weight-fragment set (t + const) % 4, and the rotation is laid out from the END of
+// the reduction so that every set index is a literal (a run-time phase switch around the K-block bodies cost the register
+// allocator 1400 spills): a K block uses sets (0,1) or (2,3); the last two blocks are always (0,1), (2,3), the steady blocks
+// before them whole [(0,1), (2,3)] pairs preceded, for an odd count, by one (2,3) block.
+template <int MODE, int ODD, int kBW>
+__global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8GemmParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- tile: XCD x owns the contiguous range [xs, xs + xl) of (m-tile, column tile) pairs, column tiles fastest: the column
+    //      tiles of an m-tile share its gathered rows, the m-tiles of an expert its weights, both inside one L2 ----
+    const int nmt = p.num_tiles[0];
+    const int live = nmt * p.n_tiles;
+    int L;
+    {
+        const int x = blockIdx.x & 7, q = live >> 3, r = live & 7;
+        const int xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int xl = q + (x < r ? 1 : 0);
+        const int jt = blockIdx.x >> 3;
+        if (jt >= xl) return;
+        L = xs + jt;
+    }
+#ifdef SGLK_DEV_ABLATE
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#define SGLK_STAMP(i) do { if (p.dbg && tid == 0) p.dbg[32 * L + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SGLK_STAMP(i) do { } while (0)
+#endif
+    const int mtile = L / p.n_tiles, ntile = L - mtile * p.n_tiles;
+    const int4 ti = p.tile_info[mtile];
+    const int e = __builtin_amdgcn_readfirstlane(ti.x);
+    const int pos0 = __builtin_amdgcn_readfirstlane(ti.y);
+    const int rows = __builtin_amdgcn_readfirstlane(ti.z);
+
+    const int ctiles = p.C >> 6;      // 64-wide k groups = stages
+    const int kblocks = p.C >> 7;
+    const int T = ctiles;
+
+    // the workgroup's 16 packed 16-row weight pieces: GATE_UP = 8 gate + the 8 matching up pieces, DOWN = 16 consecutive
+    auto piece_row16 = [&](int piece) __attribute__((always_inline)) {
+        if (MODE == MODE_GATE_UP) return (piece < 8) ? ntile * 8 + piece : (p.n_half >> 4) + ntile * 8 + (piece - 8);
+        return ntile * 16 + piece;
+    };
+
+    // ---- prologue loads (parked in registers; written to the LDS tables after the first operand loads have been issued) ----
+    float* sc = reinterpret_cast<float*>(smem + kScaleOff);          // sc[piece][kb]
+    unsigned char* xs_tab = smem + kXsOff;                             // xs_tab[kb][token row]
+    int* slot_tab = reinterpret_cast<int*>(smem + kRowTabOff);
+    float* tw_tab = reinterpret_cast<float*>(smem + kRowTabOff + kBM * 4);
+    float sc_reg[2];
+    {
+        const float* scale_e = p.w_scale + (int64_t)e * p.scale_rows * p.scale_cols;
+        const float inv_bn = 1.0f / (float)p.block_n;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * 256, piece = i >> 5, kb = i & (kMaxKB - 1);
+            sc_reg[j] = 0.f;
+            if (kb < kblocks) {
+                // floor(row / block_n) through one float multiply (exact for rows < 2^20, see moe_gemm_fp8w_256i.hip)
+                const int srow = (int)(((float)(piece_row16(piece) * 16) + 0.5f) * inv_bn);
+                sc_reg[j] = scale_e[srow * p.scale_cols + kb];
+            }
+        }
+    }
+    int my_slot = -1;
+    float my_tw = 0.f;
+    unsigned xs_reg[kMaxKB / 4];
+#pragma unroll
+    for (int i = 0; i < kMaxKB / 4; ++i) xs_reg[i] = 0x7f7f7f7fu;
+    if (tid < kBM && tid < rows) {
+        const int slot = p.sorted_slot[pos0 + tid];
+        const int64_t xrow = (MODE == MODE_GATE_UP) ? (int64_t)(slot / p.topk) : (int64_t)(pos0 + tid);
+        const unsigned* sp = reinterpret_cast<const unsigned*>(p.xs + xrow * p.xs_stride);
+#pragma unroll
+        for (int i = 0; i < kMaxKB / 4; ++i)
+            if (i * 4 < kblocks) xs_reg[i] = sp[i];
+        if (MODE == MODE_DOWN) my_slot = slot;   // its routing weight (a dependent load) is fetched near the end of the main loop
+    }
+
+    // ---- operand sources.  X: descriptor + one 32-bit lane offset per 1-KiB piece (8 rows x 128 B: lane = row l >> 3, chunk
+    //      l & 7; image chunk = logical chunk ^ ((row >> 1) & 7), applied to the SOURCE address since an LDS-DMA lands
+    //      lane-linear); the stage offset is the scalar soffset.  Rows past the tile's last one get an offset outside the
+    //      descriptor's range and fetch nothing. ----
+    const unsigned xbytes = (unsigned)__builtin_amdgcn_readfirstlane((int)p.x_bytes);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xbytes, 0x00020000);
+    const unsigned char* wexp = p.w + (int64_t)e * p.w_expert_stride;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)wexp, 0, (unsigned)p.w_expert_stride, 0x00020000);
+    unsigned xsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wn * 4 + i) * 8 + (lane >> 3);
+        unsigned off = xbytes;
+        if (r < rows) {
+            int64_t xrow;
+            if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[pos0 + r] / p.topk);
+            else xrow = (int64_t)(pos0 + r);
+            off = (unsigned)(xrow * p.x_stride) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) << 4);
+        }
+        xsrc[i] = off;
+    }
+    auto issue_x = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // piece i (0..3) of this wave, stage kt
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_s1_t)(smem + buf * kStageX + (wn * 4 + i) * 1024), 16, xsrc[i],
+                                                 kt * 128, 0, 0);
+    };
+
+    // W: lane l (r32 = l & 31 = operand row, h = l >> 5 = which 32 of the stage's 64 k) of 32-row tile rt takes slots
+    // (2h) * 16 + (r32 & 15) and + 16 of packed piece wpiece0[rt] + (r32 >> 4): 2 x 16 bytes = the operand's 32 bytes
+    const int h = lane >> 5, r32 = lane & 31;
+    int wpiece0[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        if (MODE == MODE_GATE_UP) wpiece0[rt] = rt == 0 ? wn * 2 : 8 + wn * 2;    // gate rows, matching up rows
+        else wpiece0[rt] = wn * 4 + rt * 2;
+    }
+    unsigned wsrc[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+        wsrc[rt] = (unsigned)(piece_row16(wpiece0[rt] + (r32 >> 4)) * ctiles) * 1024u + (unsigned)(((2 * h) * 16 + (r32 & 15)) * 16);
+    i32x8 fa[4][2] = {};                   // [(stage + const) % 4][row tile]
+    auto ld_a = [&](int as, int rt, int kt) __attribute__((always_inline)) {
+        const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[rt], kt * 1024, 0);
+        const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[rt], kt * 1024 + 256, 0);   // + 16 slots: in the scalar offset
+        fa[as][rt] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+
+    // B (tokens), token tile tt: row = tt * 32 + r32; hi chunks 2h, 2h + 1, lo chunks 4 + 2h, 5 + 2h, each ^ ((row >> 1) & 7),
+    // which only depends on r32; token tile tt is + tt * 4096 bytes (an immediate)
+    const int sw = (r32 >> 1) & 7;
+    const int xo_h0 = r32 * 128 + (((2 * h) ^ sw) << 4), xo_h1 = r32 * 128 + (((2 * h + 1) ^ sw) << 4);
+    const int xo_l0 = r32 * 128 + (((4 + 2 * h) ^ sw) << 4), xo_l1 = r32 * 128 + (((5 + 2 * h) ^ sw) << 4);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0.f;
+
+    // ---- prologue: X(0) A(0) X(1) A(1) X(2) A(2) X(3) in flight (in this order: the counted waits below rely on it) ----
+    constexpr int kSet0 = ODD ? 2 : 0;   // fragment set of stage 0 (K block 0 is a (2,3) block when the count is odd)
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_x(st, st, i);
+        ld_a((kSet0 + st) % 4, 0, st);
+        ld_a((kSet0 + st) % 4, 1, st);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_x(3, 3, i);
+    sc[tid] = sc_reg[0];
+    sc[tid + 256] = sc_reg[1];
+    if (tid < kBM) {
+#pragma unroll
+        for (int i = 0; i < kMaxKB / 4; ++i)
+            if (i * 4 < kblocks) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) xs_tab[(i * 4 + b) * kBM + tid] = (unsigned char)(xs_reg[i] >> (8 * b));
+            }
+        if (MODE == MODE_DOWN) slot_tab[tid] = my_slot;
+    }
+    __builtin_amdgcn_s_waitcnt(wc(20, 0));   // X(0) and A(0) have landed; X(1) A(1) X(2) A(2) X(3) = 20 operations stay in flight
+    __builtin_amdgcn_s_barrier();
+
+    int ea[2], ea_next[2];
+    float mant[2], ratio[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        split_scale(sc[wpiece0[rt] * kMaxKB], ea[rt], mant[rt]);
+        ea_next[rt] = ea[rt];
+        ratio[rt] = 1.f;
+    }
+    // B scale bytes of the lane's four tokens for the current K block (the lo term's scale is this - 4); token tile tt's byte
+    // of the NEXT block is read into the same register right behind the tile's last MFMA of the block
+    int xsv[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) xsv[tt] = xs_tab[tt * 32 + r32];
+
+#define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // Windows of token fragments (hi / lo of a 32-token tile).  kBW = 1: the next tile's fragment is requested right behind the
+    // last MFMA that reads the current one, two to three MFMAs (128+ cycles) ahead of its first use; kBW = 2: into the other
+    // window, four MFMAs ahead (16 more registers)
+    i32x8 bh[kBW] = {}, bl[kBW] = {};
+    float nsc[2] = {0.f, 0.f};
+    auto ld_bh = [&](int tt, int buf) __attribute__((always_inline)) {
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_h0) + tt * 4096);
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_h1) + tt * 4096);
+        bh[tt & (kBW - 1)] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    };
+    auto ld_bl = [&](int tt, int buf) __attribute__((always_inline)) {
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_l0) + tt * 4096);
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_l1) + tt * 4096);
+        bl[tt & (kBW - 1)] = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    };
+    // MFMA slot s of a stage (16 per wave): token tile s >> 2, then hi x rt0, hi x rt1, lo x rt0, lo x rt1
+    auto mma = [&](int as, int s2) __attribute__((always_inline)) {
+        const int tt = s2 >> 2, lo = (s2 >> 1) & 1, rt = s2 & 1;
+        if (lo)
+            acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bl[tt & (kBW - 1)], acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt] - 4);
+        else
+            acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bh[tt & (kBW - 1)], acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
+    };
+    auto rescale = [&](int rt, int tt) __attribute__((always_inline)) {   // accumulator into units of the next K block's mantissa
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][i]) : "s"(ratio[rt]));
+    };
+
+    int buf = 0;
+    SGLK_STAMP(19);
+#ifdef SGLK_DEV_ABLATE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Stage t (ring slot `buf`, weight fragments fa[as]); every flag is a literal at the call site.
+    //   first  : first stage of a K block -- the weight scale switches, token tile 3's accumulators are rescaled (slots 1, 2)
+    //   pre    : first stage of a K block that is not the last: the NEXT block's weight scales are read from the LDS table
+    //   bound  : closing stage of a K block that is not the last -- rescale token tiles 0..2 (slots 5,6 / 9,10 / 13,14) and read
+    //            the next block's activation scale bytes (behind each token tile's last MFMA)
+    //   lda    : stage t+3 exists: its weight fragments are requested (slots 2, 4) into fa[(as + 3) % 4], dead since stage t-1
+    //   wait   : >= 0: stage t+1 exists; sync point after slot 13 = s_waitcnt vmcnt(wait) (X(t+1) and A(t+1) have landed; X / A of
+    //            stages t+2 and t+3, 16 operations, may stay in flight) + lgkmcnt(0) + barrier.  Every fragment of THIS stage has
+    //            been read by then, so afterwards X(t+4) goes into this stage's ring slot and the first fragments of stage t+1
+    //            are read
+    //   dmax   : stage t+4 exists
+    auto stage = [&](int as, int t, bool first, bool bound, int wait, bool dmax, bool lda, bool pre) __attribute__((always_inline)) {
+        int nbuf = buf + 1;
+        if (nbuf == kRing) nbuf = 0;
+        const int as3 = (as + 3) % 4;
+        if (first) {   // this block's weight scale (computed one stage ago) becomes current
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) ea[rt] = ea_next[rt];
+        }
+        if (pre) {
+            const int kb = (t >> 1) + 1;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) nsc[rt] = sc[wpiece0[rt] * kMaxKB + kb];
+        }
+        if (bound) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float nm;
+                split_scale(nsc[rt], ea_next[rt], nm);
+                ratio[rt] = uniform_f32(mant[rt] * __builtin_amdgcn_rcpf(nm));
+                mant[rt] = nm;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            mma(as, s2);
+            SGLK_FENCE();
+            const int tt = s2 >> 2, q = s2 & 3;
+            if (kBW == 1) {   // the hi fragment is free after the tile's second MFMA, the lo fragment after its fourth
+                if (q == 1 && tt < 3) ld_bh(tt + 1, buf);
+                if (q == 3 && tt < 3) ld_bl(tt + 1, buf);
+            } else {          // the other window has been free since the previous tile's last MFMA
+                if (q == 0 && tt < 3) ld_bh(tt + 1, buf);
+                if (q == 1 && tt < 3) ld_bl(tt + 1, buf);
+            }
+            if (q == 3 && bound) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
+            if (s2 == 2 && lda) ld_a(as3, 0, t + 3);
+            if (s2 == 4 && lda) ld_a(as3, 1, t + 3);
+            if (first && s2 == 1) rescale(0, 3);
+            if (first && s2 == 2) rescale(1, 3);
+            if (bound && (s2 == 5 || s2 == 9 || s2 == 13)) rescale(0, (s2 - 5) >> 2);
+            if (bound && (s2 == 6 || s2 == 10 || s2 == 14)) rescale(1, (s2 - 6) >> 2);
+            if (s2 == 13 && wait >= 0) {
+                if (wait == 16) __builtin_amdgcn_s_waitcnt(wc(16, 0));
+                else if (wait == 8) __builtin_amdgcn_s_waitcnt(wc(8, 0));
+                else __builtin_amdgcn_s_waitcnt(wc(0, 0));
+                __builtin_amdgcn_s_barrier();
+                ld_bh(0, nbuf);
+                if (kBW == 2) ld_bl(0, nbuf);
+            }
+            if (s2 == 14 && dmax) { issue_x(t + 4, buf, 0); issue_x(t + 4, buf, 1); }
+            if (kBW == 1 && s2 == 15 && wait >= 0) ld_bl(0, nbuf);
+            if (s2 == 15 && dmax) { issue_x(t + 4, buf, 2); issue_x(t + 4, buf, 3); }
+            SGLK_FENCE();
+        }
+        buf = nbuf;
+    };
+    // One 128-wide K block = two stages with weight-fragment sets (a0, a0 + 1), a0 a literal; kind (a literal):
+    //   STEADY : both stages request their t+3 weights and t+4 activations
+    //   PENULT : block kblocks-2: stage T-4 requests A(T-1) and nothing else, stage T-3 nothing; the waits shrink accordingly
+    //   LAST   : block kblocks-1: stage T-2 waits for everything, stage T-1 has nothing to wait for
+    auto kblock = [&](int a0, int kind, int kb) __attribute__((always_inline)) {
+        const int t = 2 * kb;
+        if (kind == KB_STEADY) {
+            stage(a0, t, true, false, 16, true, true, true);
+            stage(a0 + 1, t + 1, false, true, 16, true, true, false);
+        } else if (kind == KB_PENULT) {
+            stage(a0, t, true, false, 16, false, true, true);
+            stage(a0 + 1, t + 1, false, true, 8, false, false, false);
+        } else {
+            if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];   // covered by stage T-2's vmcnt(0)
+            stage(a0, t, true, false, 0, false, false, false);
+            stage(a0 + 1, t + 1, false, false, -1, false, false, false);
+        }
+    };
+
+    ld_bh(0, 0);
+    ld_bl(0, 0);
+    SGLK_FENCE();
+    {
+        int kb = 0;
+        if (ODD) kblock(2, KB_STEADY, kb++);
+        for (; kb + 2 <= kblocks - 2; kb += 2) {
+            kblock(0, KB_STEADY, kb);
+            kblock(2, KB_STEADY, kb + 1);
+        }
+        kblock(0, KB_PENULT, kb);
+        kblock(2, KB_LAST, kb + 1);
+    }
+#undef SGLK_FENCE
+    SGLK_STAMP(20);
+#ifdef SGLK_DEV_ABLATE
+    if (p.dbg && tid == 0) {   // shader clocks / 100 MHz ticks over the main loop -> the clock the chip held
+        p.dbg[32 * L + 0] = __builtin_amdgcn_s_memtime() - clk0;
+        p.dbg[32 * L + 1] = p.dbg[32 * L + 20] - p.dbg[32 * L + 19];
+    }
+#endif
+    if (MODE == MODE_DOWN && tid < kBM) tw_tab[tid] = my_tw;
+
+    // ---- epilogue (ring dead).  32x32 accumulator: lane = token column (l & 31); register i = weight row
+    //      (i & 3) + 8 * (i >> 2) + 4 * (l >> 5) of the row tile ----
+    __syncthreads();
+    SGLK_STAMP(25);
+    int tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    const int r32e = tidv & 31, he = (tidv >> 5) & 1;
+    if (MODE == MODE_GATE_UP) {
+        // ic1 = bf16(silu(gate) * up) -- rounded to bf16 ONCE, as the bf16 kernel does -- for this workgroup's 128 columns = one K
+        // block of GEMM-2, then split exactly like `hidden`: per-token amax over the four waves, power-of-two scale, (hi, lo),
+        // stored [hi 64 | lo 64] per 64 group in the packed-tile k order
+        float* amax_tab = reinterpret_cast<float*>(smem + kAmaxOff);
+        float v[4][16];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float am = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const float g0 = acc[0][tt][i] * mant[0], u0 = acc[1][tt][i] * mant[1];
+                const float g1 = acc[0][tt][i + 1] * mant[0], u1 = acc[1][tt][i + 1] * mant[1];
+                const unsigned pk = pack_bf16x2(silu_f32(g0) * u0, silu_f32(g1) * u1);
+                v[tt][i] = __uint_as_float(pk << 16);
+                v[tt][i + 1] = __uint_as_float(pk & 0xffff0000u);
+                am = fmaxf(am, fmaxf(fabsf(v[tt][i]), fabsf(v[tt][i + 1])));
+            }
+            am = fmaxf(am, __shfl_xor(am, 32));
+            if (he == 0) amax_tab[wn * kBM + tt * 32 + r32e] = am;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int r = tt * 32 + r32e;
+            const float am = fmaxf(fmaxf(amax_tab[r], amax_tab[kBM + r]), fmaxf(amax_tab[2 * kBM + r], amax_tab[3 * kBM + r]));
+            const int sb = sp_e8m0_for_amax(am);
+            if (wn == 0 && he == 0 && r < rows) p.out_s[(int64_t)(pos0 + r) * p.out_s_stride + ntile] = (uint8_t)sb;
+            unsigned char* rowp = smem + r * 256;      // image row: [group 0: hi 64 | lo 64][group 1: hi 64 | lo 64]
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {           // register groups 2rp, 2rp + 1 = eight values = two dwords of hi and of lo
+                unsigned hi[2], lo[2];
+                split8(&v[tt][rp * 8], sb, hi, lo);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int rg = rp * 2 + q;
+                    // columns wn*32 + rg*8 + he*4 .. +3 of the 128: 64 group wn >> 1, k = (wn & 1)*32 + rg*8 + he*4
+                    //   -> position 32*(rg >> 1) + 8*(wn & 1) + 16*(rg & 1) + 4*he inside the group's hi (and lo) half
+                    const int pos = 32 * (rg >> 1) + 8 * (wn & 1) + 16 * (rg & 1) + 4 * he;
+                    const int bh_ = (wn >> 1) * 128 + pos, bl_ = bh_ + 64;
+                    *reinterpret_cast<unsigned*>(rowp + (((bh_ >> 4) ^ (r & 15)) << 4) + (bh_ & 15)) = hi[q];
+                    *reinterpret_cast<unsigned*>(rowp + (((bl_ >> 4) ^ (r & 15)) << 4) + (bl_ & 15)) = lo[q];
+                }
+            }
+        }
+        SGLK_STAMP(26);
+        __syncthreads();
+        SGLK_STAMP(27);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = it * 256 + tidv;
+            const int r = idx >> 4, pc = idx & 15, lc = pc ^ (r & 15);
+            if (r < rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + r * 256 + pc * 16);
+                *reinterpret_cast<uint4*>((unsigned char*)p.out + (int64_t)(pos0 + r) * p.out_stride + ntile * 256 + lc * 16) = val;
+            }
+        }
+    } else {
+        // ic2[slot] = topk_w * (acc * mant) in bf16: XOR-swizzled [token][256 columns] image, whole rows out by slot
+        constexpr int kRowB = 512;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int r = tt * 32 + r32e;
+            unsigned char* rowp = smem + r * kRowB;
+            const float tw = tw_tab[r];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float sc_w = mant[rt] * tw;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    uint2 val;
+                    val.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w, acc[rt][tt][rg * 4 + 1] * sc_w);
+                    val.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w, acc[rt][tt][rg * 4 + 3] * sc_w);
+                    const int col = wn * 64 + rt * 32 + rg * 8 + he * 4;
+                    const int chunk = (col >> 3) ^ (r & 15);
+                    *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = val;
+                }
+            }
+        }
+        SGLK_STAMP(26);
+        __syncthreads();
+        SGLK_STAMP(27);
+        uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tidv;
+            const int r = idx >> 5, pc = idx & 31, lc = pc ^ (r & 15);
+            if (r < rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
+                *reinterpret_cast<uint4*>(outp + (int64_t)slot_tab[r] * p.out_stride + ntile * 256 + lc * 8) = val;
+            }
+        }
+    }
+#ifdef SGLK_DEV_ABLATE
+    if (p.dbg && tid == 0) {
+        p.dbg[32 * L + 18] = rt_entry;
+        p.dbg[32 * L + 22] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        p.dbg[32 * L + 23] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+        p.dbg[32 * L + 21] = __builtin_amdgcn_s_memrealtime();   // stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p.dbg[32 * L + 24] = __builtin_amdgcn_s_memrealtime();   // stores acknowledged
+    }
+#endif
+#undef SGLK_STAMP
+}
+
+}  // namespace gs128
+
+bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n) {
+    // both reductions (K for GEMM-1, N for GEMM-2) in whole 128-wide blocks, 2 .. 32 of them; 128 ic1 columns / 256 output
+    // columns per workgroup; a 32-row operand tile inside one scale block
+    return K % 256 == 0 && N % 128 == 0 && K >= 256 && N >= 256 && K <= 128 * gs128::kMaxKB && N <= 128 * gs128::kMaxKB &&
+           block_n % 32 == 0;
+}
+
+int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream) {
+    int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
+    if (blocks == 0) return SGLK_OK;
+    blocks = (blocks + 7) / 8 * 8;   // every XCD's share of the tile list must be reachable (blockIdx >> 3)
+    const int kblocks = p.C >> 7;
+    if (p.C % 128 != 0 || kblocks < 2 || kblocks > gs128::kMaxKB)
+        SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: reduction length %d (needs 2..%d whole 128-wide K blocks)", p.C, gs128::kMaxKB);
+    if (p.block_n % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: block_n %d is not a multiple of 32", p.block_n);
+    if (p.xs_stride % 4 != 0 || ((uintptr_t)p.xs % 4) != 0) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: scale rows must be 4-byte aligned");
+    if (mode != MODE_GATE_UP && mode != MODE_DOWN) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: mode %d", mode);
+    const int odd = kblocks & 1;
+    const int bw = knobs().s128_bw == 2 ? 2 : 1;
+#define SGLK_LAUNCH_S128(M_, O_, B_) \
+    hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, O_, B_>), dim3((unsigned)blocks), dim3(256), 0, stream, p)
+#define SGLK_LAUNCH_S128_B(M_, O_) do { if (bw == 2) SGLK_LAUNCH_S128(M_, O_, 2); else SGLK_LAUNCH_S128(M_, O_, 1); } while (0)
+    if (mode == MODE_GATE_UP) {
+        if (odd) SGLK_LAUNCH_S128_B(MODE_GATE_UP, 1);
+        else SGLK_LAUNCH_S128_B(MODE_GATE_UP, 0);
+    } else {
+        if (odd) SGLK_LAUNCH_S128_B(MODE_DOWN, 1);
+        else SGLK_LAUNCH_S128_B(MODE_DOWN, 0);
+    }
+#undef SGLK_LAUNCH_S128_B
+#undef SGLK_LAUNCH_S128
+    SGLK_CHECK_LAUNCH("moe_gemm_fp8w_s128");
+    return SGLK_OK;
+}
+
+}  // namespace sglk

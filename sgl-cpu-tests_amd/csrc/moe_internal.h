@@ -86,6 +86,10 @@ int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStrea
 // W8A16 with EXACT bf16 activations as two e4m3 terms (hi + lo) on the block-scaled fp8 matrix cores (moe_gemm_fp8w_split.hip):
 // x / ic1 rows are [hi 64 | lo 64] per 64-wide k group (x_stride / out_stride = 2 * C bytes), one E8M0 byte per 128 block
 int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+// the same contract on 128-token tiles, four waves, two workgroups per CU, weights streamed global -> VGPR
+// (moe_gemm_fp8w_s128.hip); tile table built with tile_m = 128; GATE_UP n_tiles = N / 128, DOWN n_tiles = K / 256
+int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n);
 int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
                               int64_t rows, int cols, hipStream_t stream);
 // hidden bf16 [rows][cols] -> e4m3 (packed-tile k order) + one E8M0 byte per 128-wide block

@@ -167,3 +167,94 @@ def test_split_kernel_bench_sizes(ops, knob, qwen3, M):
     out_b = bp.call(ops, q, a, tw, ids)
     rel = (out.float() - out_b.float()).norm() / out_b.float().norm()
     assert rel < 3e-3, f"split vs bf16-MFMA kernel: {rel:.2e}"
+
+
+# ---- the same split on 128-token tiles, four waves, two workgroups per CU (sgl-cpu-tests_amd/csrc/moe_gemm_fp8w_s128.hip) ----------
+
+def s128_taken():
+    from sgl_kernel import _lib, _ops
+    return bool(_ops.last_path & _lib.PATH_SPLIT) and (_ops.last_path & _lib.PATH_TILE_MASK) == 128
+
+
+@pytest.mark.parametrize("name", ["m1212_n512_k1024_e8_t2", "masked_m300_n256_k512_e16_t8", "qwen3dims_m96_e8_t8"])
+def test_s128_kernel_golden(ops, knob, name):
+    """Golden cases of the reference's own oracle (tests/golden/make_golden.py), reference predicate + relative RMS, run-to-run
+    bit identity, and agreement with the 256-row split kernel (same arithmetic, other tiling) and the bf16-MFMA kernel."""
+    case = next(c for c in recipes.MOE_FP8_CASES if c[0] == name)
+    _, M, N, K, E, topk, bn, bk, masked, seed, _full = case
+    g, _ = load_golden("moe_fp8_" + name)
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed)
+    knob(SGLK_S128=1, SGLK_MOE_TILE_M=256, SGLK_TAIL_SPLIT=0)
+    out = run(ops, inp, (bn, bk))
+    assert s128_taken()
+    e_s = check_close(out, g["ref_out_f32"], name + " (s128)")
+    again = run(ops, inp, (bn, bk))
+    assert torch.equal(out, again), "run-to-run bit identity"
+    knob(SGLK_S128=0, SGLK_SPLIT=1)
+    ref_k = run(ops, inp, (bn, bk))
+    assert not s128_taken()
+    rel = (out.float() - ref_k.float()).norm() / ref_k.float().norm()
+    print(f"[s128] {name}: rel RMS vs oracle {e_s:.2e}; vs the 256-row split kernel {rel:.2e}")
+    assert rel < 2e-3
+
+
+def test_s128_kernel_scale_extremes_and_wide_activations(ops, knob):
+    knob(SGLK_S128=1, SGLK_MOE_TILE_M=256, SGLK_TAIL_SPLIT=0)
+    M, N, K, E, topk, bn, bk = 1531, 256, 512, 8, 4, 128, 128
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 9001)
+    g = torch.Generator().manual_seed(5)
+    inp["w1s"] = inp["w1s"].sign() * torch.exp2(torch.rand(inp["w1s"].shape, generator=g) * 16 - 12) * 1e-2
+    inp["w1s"][0, 0, 0] = 0.0
+    inp["w2s"][1, 0, 0] = 0.0
+    inp["w2s"][2, 1, 1] = 2.0 ** -9
+    a = inp["a"].float()
+    a[::7, 3::128] *= 4096.0
+    inp["a"] = a.bfloat16()
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    out = run(ops, inp, (bn, bk))
+    assert s128_taken()
+    check_close(out, ref * k, "s128: scale extremes + wide activations")
+
+
+@pytest.mark.parametrize("N,K,E,topk,M", [(256, 256, 4, 2, 700),      # both reductions two K blocks long (the shortest legal)
+                                          (384, 768, 8, 4, 900),      # three / six blocks: every (kblocks - 2) % 3 phase ...
+                                          (512, 1280, 8, 2, 1300),    # ... four / ten
+                                          (640, 1024, 4, 2, 777)])    # five / eight; ragged last tiles throughout
+def test_s128_kernel_reduction_lengths(ops, knob, N, K, E, topk, M):
+    """The kernel rotates three weight-fragment register sets and is compiled per (kblocks - 2) % 3: every phase, the shortest
+    reduction and ragged tiles against the C oracle."""
+    knob(SGLK_S128=1, SGLK_MOE_TILE_M=256, SGLK_TAIL_SPLIT=0)
+    bn, bk = 128, 128
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 77 + N + K)
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    out = run(ops, inp, (bn, bk))
+    assert s128_taken()
+    check_close(out, ref * k, f"s128 N={N} K={K}")
+
+
+@pytest.mark.parametrize("M", [4096, 16384])
+def test_s128_kernel_bench_sizes(ops, knob, qwen3, M):
+    """Qwen3-30B-A3B dims, all 128 experts, the sizes bench.py runs: >= 256 sampled tokens (every expert, full and tail tiles)
+    against the C oracle, in place == out of place, and agreement with the bf16-MFMA kernel."""
+    import test_moe_fp8_bench_path_gpu as bp
+    a, tw, ids = bp.routed_inputs(M, 200 + M)
+    knob(SGLK_S128=1)
+    q = qwen3
+    out = bp.call(ops, q, a, tw, ids)
+    assert s128_taken()
+    assert torch.isfinite(out.float()).all()
+    toks, fulls, tails, hit = bp.sample_tokens(ids, bp.E)
+    assert hit == bp.E and len(toks) >= 256
+    ref = c_oracle.fused_experts_fp8(a[toks].cpu(), q["w1"], q["w2"], q["w1s"].cpu(), q["w2s"].cpu(), (bp.BN, bp.BK),
+                                     tw[toks].cpu(), ids[toks].cpu())
+    bp.check_close(out[toks], ref, f"s128 qwen3 M={M}")
+    again = bp.call(ops, q, a, tw, ids)
+    assert torch.equal(out, again), "run-to-run bit identity"
+    knob(SGLK_S128=0, SGLK_SPLIT=0)
+    out_b = bp.call(ops, q, a, tw, ids)
+    rel = (out.float() - out_b.float()).norm() / out_b.float().norm()
+    assert rel < 3e-3, f"s128 vs bf16-MFMA kernel: {rel:.2e}"

@@ -47,5 +47,42 @@ for name, full in (("GEMM-1", both[0]), ("GEMM-2", both[1])):
         if len(sel) > 1:
             gaps.append(sel[1:, 18] - sel[:-1, 24])
     gaps = torch.cat(gaps)
+    # co-resident workgroups (two per CU on the 128-token kernels): share of a CU's busy span in which at least one / more than
+    # one workgroup is inside its main loop (the matrix pipe has work / is shared)
+    cov1, cov2 = [], []
+    for c in cu.unique():
+        sel = full[cu == c]
+        ev = sorted([(float(x), 1) for x in sel[:, 19]] + [(float(x), -1) for x in sel[:, 20]])
+        span = float(sel[:, 24].max() - sel[:, 18].min())
+        depth, last, t1, t2 = 0, ev[0][0], 0.0, 0.0
+        for t, d in ev:
+            if depth >= 1: t1 += t - last
+            if depth >= 2: t2 += t - last
+            depth += d
+            last = t
+        cov1.append(t1 / span)
+        cov2.append(t2 / span)
+    cov1, cov2 = torch.tensor(cov1), torch.tensor(cov2)
+    # rate of a workgroup's main loop alone on its CU (r1) and beside a co-resident main loop (r2, per workgroup): least squares
+    # of  1 = d_alone * r1 + d_shared * r2  over the workgroups (units: main loops per us)
+    rows_a, rows_b = [], []
+    for c in cu.unique():
+        sel = full[cu == c]
+        for i in range(len(sel)):
+            a0, a1 = float(sel[i, 19]), float(sel[i, 20])
+            sh = 0.0
+            for j in range(len(sel)):
+                if j != i:
+                    sh += max(0.0, min(a1, float(sel[j, 20])) - max(a0, float(sel[j, 19])))
+            rows_a.append((a1 - a0 - sh) / 100.0)
+            rows_b.append(sh / 100.0)
+    A = torch.tensor([rows_a, rows_b], dtype=torch.float64).T
+    sol = torch.linalg.lstsq(A, torch.ones(len(rows_a), 1, dtype=torch.float64)).solution.flatten()
+    print(f"   main loop alone on the CU: {1 / sol[0]:.2f} us per tile; beside another main loop: {1 / sol[1]:.2f} us per tile "
+          f"(= {0.5 / sol[1]:.2f} us of CU time per tile)")
+    if (full[:, 0] > 0).any():
+        clk = full[:, 0] / full[:, 1].clamp_min(1) * 100.0
+        print(f"   in-kernel clock over the main loop: median {clk.median():.0f} MHz (p10 {clk.quantile(0.1):.0f}, p90 {clk.quantile(0.9):.0f})")
+    print(f"   per CU: some workgroup in its main loop {cov1.median():.3f} of the busy span (p10 {cov1.quantile(0.1):.3f}); two or more {cov2.median():.3f}")
     print(f"   CUs seen {len(per_cu)}, workgroups per CU min/max {min(per_cu)}/{max(per_cu)}; gap between consecutive workgroups on a CU: "
           f"median {us(gaps.median()):.2f} us  p10 {us(gaps.quantile(0.1)):.2f}  p90 {us(gaps.quantile(0.9)):.2f}")
