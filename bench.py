@@ -52,29 +52,60 @@ def make_inputs(M, E_local, dev, seed):
     return a, w1, w2, w1s, w2s, tw.contiguous(), ids.to(torch.int32).contiguous()
 
 
-def cpu_baseline(tokens):
-    """Plain-C oracle (oracle/c/moe_fp8_ref.c, OpenMP) on a bounded sample of the same workload, host cores."""
+def _numa_node0_cpus():
+    """CPUs of NUMA node 0 that this process may run on (the reference pins its CPU runs to one node:
+    /root/reference/run_bench_cpu.sh:14-20), or None when the topology cannot be read."""
+    try:
+        txt = open("/sys/devices/system/node/node0/cpulist").read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        return sorted(cpus) or None
+    except Exception:
+        return None
+
+
+def cpu_baseline(a, w1, w2, w1s, w2s, tw, ids, max_tokens):
+    """Plain-C oracle (oracle/c/moe_fp8_ref.c, OpenMP) on the host cores, on the SAME inputs as the GPU run -- the same weights,
+    scales and routing, the first `max_tokens` tokens of the same batch -- with every thread of the process pinned to the
+    cores of NUMA node 0 and one OpenMP thread per core of that node, the way the reference runs its CPU benches
+    (/root/reference/run_bench_cpu.sh:14-20: OMP_NUM_THREADS=$CORES numactl --physcpubind ... --membind)."""
     from oracle import c_oracle
-    g = torch.Generator().manual_seed(99)
-    a = (torch.randn(tokens, K_HIDDEN, generator=g) / K_HIDDEN ** 0.5).bfloat16()
-    w1 = torch.randint(0, 256, (N_EXPERTS, 2 * N_INTER, K_HIDDEN), dtype=torch.uint8, generator=g)
-    w2 = torch.randint(0, 256, (N_EXPERTS, K_HIDDEN, N_INTER), dtype=torch.uint8, generator=g)
-    # keep clear of the two NaN encodings so the sample is ordinary arithmetic
-    w1[(w1 & 0x7F) == 0x7F] = 0x38
-    w2[(w2 & 0x7F) == 0x7F] = 0x38
-    w1, w2 = w1.view(torch.float8_e4m3fn), w2.view(torch.float8_e4m3fn)
-    w1s = torch.randn(N_EXPERTS, 2 * N_INTER // BLOCK[0], K_HIDDEN // BLOCK[1], generator=g) * 1e-3
-    w2s = torch.randn(N_EXPERTS, K_HIDDEN // BLOCK[0], N_INTER // BLOCK[1], generator=g) * 1e-3
-    score = torch.softmax(torch.randn(tokens, N_EXPERTS, generator=g), dim=-1)
-    tw, ids = torch.topk(score, TOPK)
-    c_oracle.fused_experts_fp8(a[:8], w1, w2, w1s, w2s, BLOCK, tw[:8], ids[:8].to(torch.int32))  # page-in / warm
-    t0 = time.perf_counter()
-    c_oracle.fused_experts_fp8(a, w1, w2, w1s, w2s, BLOCK, tw, ids.to(torch.int32))
-    dt = time.perf_counter() - t0
-    return {"value": round(tokens * FLOP_PER_TOKEN / dt / 1e12, 5), "unit": "TFLOP/s",
-            "tokens_per_s": round(tokens / dt, 1), "cores": c_oracle.num_threads(), "kind": "port",
-            "sample": f"{tokens} tokens of the same workload (all 128 experts, fp8 block-scaled weights), "
-                      f"{dt:.1f} s wall, plain-C oracle with OpenMP (build's own restatement, not upstream sgl_kernel)"}
+    n = min(int(a.shape[0]), max_tokens)
+    a, tw, ids = a[:n].cpu(), tw[:n].cpu(), ids[:n].cpu().to(torch.int32)
+    w1s, w2s = w1s.cpu(), w2s.cpu()
+    cpus = _numa_node0_cpus()
+    before = {}
+    if cpus:
+        for tid in os.listdir("/proc/self/task"):       # every thread (OpenMP workers inherit from their creator)
+            try:
+                before[int(tid)] = os.sched_getaffinity(int(tid))
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+        c_oracle.set_threads(len(cpus))
+    try:
+        c_oracle.fused_experts_fp8(a[:8], w1, w2, w1s, w2s, BLOCK, tw[:8], ids[:8])  # page-in / warm
+        t0 = time.perf_counter()
+        c_oracle.fused_experts_fp8(a, w1, w2, w1s, w2s, BLOCK, tw, ids)
+        dt = time.perf_counter() - t0
+        threads = c_oracle.num_threads()
+    finally:
+        for tid, mask in before.items():
+            try:
+                os.sched_setaffinity(tid, mask)
+            except OSError:
+                pass
+        if cpus:
+            c_oracle.set_threads(os.cpu_count() or 1)
+    where = f"pinned to NUMA node 0 ({len(cpus)} cores: {cpus[0]}-{cpus[-1]})" if cpus else "not pinned (no NUMA topology readable)"
+    return {"value": round(n * FLOP_PER_TOKEN / dt / 1e12, 5), "unit": "TFLOP/s",
+            "tokens_per_s": round(n / dt, 1), "cores": threads, "kind": "port",
+            "sample": f"the first {n} tokens of the GPU run's own batch, same fp8 weights / block scales / routing (all 128 "
+                      f"experts), {dt:.1f} s wall, {where}, plain-C oracle with OpenMP (build's own restatement, not upstream "
+                      f"sgl_kernel)"}
 
 
 def main():
@@ -84,7 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=int(os.environ.get("SGLK_BENCH_TOKENS", 16384)),
                     help="tokens per GPU per step (BASELINE.md evaluates the MFMA roofline at M = 16384)")
-    ap.add_argument("--cpu-tokens", type=int, default=int(os.environ.get("SGLK_BENCH_CPU_TOKENS", 32768)))
+    ap.add_argument("--cpu-tokens", type=int, default=int(os.environ.get("SGLK_BENCH_CPU_TOKENS", 16384)),
+                    help="cpu_baseline: at most this many tokens of the GPU run's batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-a8", dest="a8", action="store_false",
                     help="skip the secondary measurement of the opt-in a8 mode (fp8 activations, block-scaled fp8 MFMA)")
@@ -122,7 +154,8 @@ def main():
     a, w1, w2, w1s, w2s, tw, ids = make_inputs(M, E_local, dev, 1111 + rank)
     w1p, w2p = ops.convert_weight_packed(w1), ops.convert_weight_packed(w2)
     verify = world == 1 and not args.no_verify
-    w_host = (w1.cpu(), w2.cpu()) if verify else None    # the oracle check after the timed region reads the plain weights
+    # the oracle check after the timed region and the cpu_baseline read the plain (unpacked) weights
+    w_host = (w1.cpu(), w2.cpu()) if (verify or (world == 1 and not args.no_cpu_baseline)) else None
     del w1, w2
     # inplace=True is the reference's call (bench_moe.py:113-130): every step overwrites its input.  So that no step ever
     # reads a previous step's OUTPUT (values would drift towards 0 / inf and the chip clocks differently on such data), each
@@ -294,7 +327,8 @@ def main():
         if p & _lib.PATH_FP8_ACT:
             kern = "ga8::moe_gemm_a8_kernel"
         if p & _lib.PATH_SPLIT:
-            kern = "gsp::moe_gemm_fp8w_split_kernel (bf16 activations as two exact e4m3 terms, scaled fp8 MFMA)"
+            kern = ("gs128::moe_gemm_fp8w_s128_kernel" if tile == 128 else "gsp::moe_gemm_fp8w_split_kernel") + \
+                " (bf16 activations as two exact e4m3 terms, scaled fp8 MFMA)"
         return kern, tile
 
     # ---- oracle check of the LAST timed step's output (outside the timed region): >= 64 token rows through the plain-C
@@ -306,12 +340,17 @@ def main():
         sample = torch.arange(0, M, max(1, M // n_s), device=dev)[:n_s]
         ref = c_oracle.fused_experts_fp8(a[sample].cpu(), w_host[0], w_host[1], w1s.cpu(), w2s.cpu(), BLOCK,
                                          tw[sample].cpu(), ids[sample].cpu())
+        # one more step of exactly the timed call on a pristine copy of the tokens, outside the timed region: with inplace=True
+        # the timed steps overwrite their inputs, and beyond 96 steps the input clones are reused
+        inputs[step_idx[0] % n_inputs].copy_(a)
+        step()
+        torch.cuda.synchronize()
         got = last["out"][sample].cpu()
         diff = (got.float() - ref).abs().max().item()
         rel = ((got.float() - ref).norm() / ref.norm().clamp_min(1e-12)).item()
         ok = bool(torch.allclose(ref.bfloat16(), got, rtol=1e-2, atol=1e-2)) and rel < 6e-3
         verified = {"ok": ok, "rows": int(sample.numel()), "max_abs_diff": round(diff, 6), "rel_rms": round(rel, 6),
-                    "against": "oracle/c/moe_fp8_ref.c on the last timed step's output; predicate allclose(rtol=atol=1e-2) "
+                    "against": "oracle/c/moe_fp8_ref.c on the output of the timed call repeated once on pristine tokens; predicate allclose(rtol=atol=1e-2) "
                                "(/root/reference/utils.py:9-13) and relative RMS < 6e-3"}
 
     if rank == 0:
@@ -354,7 +393,8 @@ def main():
                        "tokens_per_gpu": M, "experts_per_gpu": E_local, "priming_steps_before_warmup": prime,
                        "parallelism": "single GPU" if world == 1 else
                        (f"ep{world} (RCCL all-to-all dispatch/combine" +
-                        (f", {len(streams)} steps in flight on separate HIP streams)" if streams else ")")
+                        (f", pipelined over {len(streams)} HIP streams: {len(streams)} steps in flight, so this is throughput, "
+                         f"not the latency of one step)" if streams else ")")
                         if backend == "nccl" else
                         f"ep{world} REHEARSAL over {backend}, host-staged payloads, ranks sharing GPUs: not a measurement")},
             "verified": verified["ok"] if verified else None,
@@ -364,8 +404,10 @@ def main():
                          "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_calls, "avg_launch_ms": round(dom_ms, 4),
                          "algorithmic_flop_per_launch": dom_flop,
-                         "note": "W8A16: fp8 weights are converted exactly to bf16 in registers and multiplied on "
-                                 "bf16 MFMA, so the dense bf16 peak (2.5 PF) is the governing roof"},
+                         "note": "W8A16 with exact products: each bf16 activation enters as two e4m3 terms on the block-scaled "
+                                 "fp8 MFMA (2 x the bf16 rate, 2 instructions per product) or, on the bf16-MFMA kernels, the "
+                                 "fp8 weights are converted exactly to bf16 -- either way the dense bf16 peak (2.5 PF) is the "
+                                 "governing roof"},
             "stage_ms": stage_ms,
         }
         if world > 1:
@@ -384,7 +426,7 @@ def main():
                 line["a8"] = {"value": None, "error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_tokens)
+                line["cpu_baseline"] = cpu_baseline(a, w_host[0], w_host[1], w1s, w2s, tw, ids, args.cpu_tokens)
             except Exception as e:  # the bench line must still be printed
                 line["cpu_baseline"] = {"value": None, "error": str(e)[:200]}
         print(json.dumps(line), flush=True)

@@ -44,6 +44,12 @@ int sglk_oracle_num_threads(void) {
 #endif
 }
 
+/* bench.py's cpu_baseline pins the run to one NUMA node (like /root/reference/run_bench_cpu.sh:14-20) and sets the thread count
+ * to that node's cores */
+void sglk_oracle_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+}
+
 /* dequantise one expert matrix [R][C] fp8 with block scales [R/bn][C/bk] (ceil) into dst f32 */
 static void dequant_matrix(const uint8_t* w, const float* scale, int R, int C, int bn, int bk,
                            const float* lut, float* dst) {

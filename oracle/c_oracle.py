@@ -31,6 +31,11 @@ def num_threads():
     return lib().sglk_oracle_num_threads()
 
 
+def set_threads(n):
+    """OpenMP threads of the following calls (bench.py's cpu_baseline: the cores of one NUMA node)."""
+    lib().sglk_oracle_set_threads(int(n))
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 

@@ -13,7 +13,7 @@ using namespace sglk;
 namespace {
 
 constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
-constexpr bool kS128Default = false;    // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
+constexpr bool kS128Default = true;     // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
 
 struct StageTimer {
     int max_calls = 0, calls = 0;
@@ -82,7 +82,7 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype, int fl
     w.num_tiles = take(sizeof(int));
     w.tile_info_b = take((size_t)E * 4 * sizeof(int));   // tail tiles (at most one per expert) of the 256-row plan
     w.num_tiles_b = take(sizeof(int));
-    w.tickets = take(32 * sizeof(int));
+    w.tickets = take(16 * sizeof(int));
     w.ic1 = take((size_t)S * N * (wtype == SGLK_W_INT8 ? 4 : 2));   // W8A8 keeps SiLU*mul in fp32 until it is quantised
     w.ic2 = take((size_t)S * K * 2);
     if (wtype == SGLK_W_FP8_E4M3 && !(flags & SGLK_MOE_FP8_ACT)) {   // two-term split of `hidden` (ic1's split rows take ic1's own place)
@@ -273,11 +273,11 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     int tile_m = a8 ? 256 : tuned ? pick_tile_m(M, N, K, E, topk, a->block_n, a->hidden_stride) : (mid_b16 ? kMidTileM : (mid_i8 ? kI8MidTileM : ((tuned_i8 || tuned_b16) ? 256 : kGenericTileM)));
     // the 256-row regime on 128-token tiles, four waves, two workgroups per CU (moe_gemm_fp8w_s128.hip): the two-term split
     // whose prologue / epilogue hide behind the co-resident workgroup's main loop
+    // (the default only when no test knob pins a tiling or one of the 256-row kernels; SGLK_S128=1 / 0 forces / forbids it)
+    const bool s128_on = knobs().s128 >= 0 ? knobs().s128 == 1 : (kS128Default && knobs().moe_tile_m == 0 && knobs().split < 0);
     const bool s128 = tuned && !a8 && tile_m == 256 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (int64_t)M * K * 2 < (1ll << 32) &&
-                      (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().s128 >= 0 ? knobs().s128 == 1 : kS128Default) &&
-                      knobs().split != 0;
+                      (int64_t)M * topk * N * 2 < (1ll << 32) && s128_on;
     if (s128) tile_m = 128;
-    const bool s128p = s128 && moe_gemm_fp8w_s128_persistent();   // two tile tables: more than 96 rows / an expert's short last tile
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -317,8 +317,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     const bool inline_align = tuned && !a8 && tile_m == kStreamTileM && !route && !split_tails && (int64_t)M * topk <= inline_max;
     if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
-                                    s128p ? 96 : (split_tails ? kMidTileM : 0), tile_info_b, num_tiles_b, ws + w.align_ws,
-                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), s128p ? 1 : 0);
+                                    split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
+                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets));
     if (rc != SGLK_OK) return rc;
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
@@ -414,11 +414,6 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q1.out_stride = 2 * (int64_t)N;
         q1.out_s = ic1s;
         q1.out_s_stride = ic1s_stride;
-        if (s128p) {
-            q1.tile_info_b = (const int4*)tile_info_b;
-            q1.num_tiles_b = num_tiles_b;
-            q1.tickets = (int*)(ws + w.tickets);
-        }
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
@@ -446,11 +441,6 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q2.out = ic2;
         q2.out_stride = K;
         q2.topk_weights = a->topk_weights;
-        if (s128p) {
-            q2.tile_info_b = (const int4*)tile_info_b;
-            q2.num_tiles_b = num_tiles_b;
-            q2.tickets = (int*)(ws + w.tickets) + 16;
-        }
 #ifdef SGLK_DEV_ABLATE
         if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
 #endif

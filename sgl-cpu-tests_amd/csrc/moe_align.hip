@@ -44,15 +44,13 @@ __global__ __launch_bounds__(256) void moe_count_kernel(const int* __restrict__ 
 
 // tail_max > 0: the last of an expert's SEVERAL tiles goes to a second table (tile_info_b / num_tiles_b) when it has at most tail_max rows
 // -- fused_experts runs those tail tiles on the weight-streaming mid kernel instead of paying a full 256-row tile for them.
-// tail_any: ... of ANY expert, also when it is the expert's only tile (the 128-token split kernel: table A then holds only tiles
-// of more than tail_max rows).
-// zero16: 32 ints the caller wants cleared before its next launch (the tile tickets of the persistent GEMMs), or null.
+// zero16: sixteen ints the caller wants cleared before its next launch (the tile tickets of the persistent GEMMs), or null.
 __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ ids, int S, int E, int nbits,
                                                         const int* __restrict__ counts, int nchunk, int tile_m, int max_tiles,
                                                         int* __restrict__ sorted_slot, int* __restrict__ expert_off,
                                                         int* __restrict__ tile_info, int* __restrict__ num_tiles, int tail_max,
                                                         int* __restrict__ tile_info_b, int* __restrict__ num_tiles_b,
-                                                        int* __restrict__ zero16, int tail_any) {
+                                                        int* __restrict__ zero16) {
     __shared__ int s_tot[kMaxExperts];       // slots of the expert in the whole input
     __shared__ int s_base[kMaxExperts];      // slots of the expert in earlier chunks; after the scan: first position of MY chunk's
     __shared__ int s_run[4][kMaxExperts];    // per wave: slots of the expert placed so far by this chunk
@@ -64,7 +62,7 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
         s_base[e] = 0;
         s_run[0][e] = s_run[1][e] = s_run[2][e] = s_run[3][e] = 0;
     }
-    if (blk == 0 && zero16 && tid < 32) zero16[tid] = 0;
+    if (blk == 0 && zero16 && tid < 16) zero16[tid] = 0;
     __syncthreads();
     // my slots' ids (kept in registers) and the per-wave histograms of this chunk
     const int first = blk * kAlignChunk + wv * (kAlignChunk / 4);
@@ -106,7 +104,7 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
             const int total = s_tot[e];
             const int nt_all = (total + tile_m - 1) / tile_m;
             const int rem = total - (nt_all - 1) * tile_m;         // rows of the expert's last tile (nt_all > 0)
-            const int tail = (tail_max > 0 && nt_all >= (tail_any ? 1 : 2) && rem <= tail_max) ? 1 : 0;   // a true tail: the expert has full tiles too
+            const int tail = (tail_max > 0 && nt_all >= 2 && rem <= tail_max) ? 1 : 0;   // a true tail: the expert has full tiles too
             mine.x += total;
             mine.y += nt_all - tail;
             mine.z += tail;
@@ -135,7 +133,7 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
         const int total = s_tot[e];
         const int nt_all = (total + tile_m - 1) / tile_m;
         const int rem = total - (nt_all - 1) * tile_m;
-        const int tail = (tail_max > 0 && nt_all >= (tail_any ? 1 : 2) && rem <= tail_max) ? 1 : 0;
+        const int tail = (tail_max > 0 && nt_all >= 2 && rem <= tail_max) ? 1 : 0;
         const int off = run.x, nt = nt_all - tail;
         s_base[e] += off;
         if (blk == 0) {
@@ -193,7 +191,7 @@ __global__ __launch_bounds__(1024) void moe_align_small_kernel(const int* __rest
                                                                int tile_m, int max_tiles, int* __restrict__ sorted_slot,
                                                                int* __restrict__ expert_off, int* __restrict__ tile_info,
                                                                int* __restrict__ num_tiles, int* __restrict__ zero16) {
-    if (zero16 && threadIdx.x < 32) zero16[threadIdx.x] = 0;
+    if (zero16 && threadIdx.x < 16) zero16[threadIdx.x] = 0;
     moe_align_small_body(ids, S, E, nbits, tile_m, max_tiles, sorted_slot, expert_off, tile_info, num_tiles);
 }
 
@@ -220,7 +218,7 @@ namespace sglk {
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
                            int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
                            int32_t tail_max, int32_t* tile_info_b, int32_t* num_tiles_b,
-                           void* workspace, size_t workspace_bytes, void* stream, int32_t* zero16, int tail_any) {
+                           void* workspace, size_t workspace_bytes, void* stream, int32_t* zero16) {
     SGLK_REQUIRE(M >= 0 && E > 0 && topk > 0 && tile_m > 0, SGLK_ERR_INVALID, "moe_align: bad sizes M=%d E=%d topk=%d", M, E, topk);
     SGLK_REQUIRE(E <= kMaxExperts, SGLK_ERR_SHAPE, "moe_align: at most %d experts supported (got %d)", kMaxExperts, E);
     SGLK_REQUIRE((int64_t)M * topk < (1ll << 31), SGLK_ERR_SHAPE, "moe_align: M*topk overflows int32");
@@ -245,7 +243,7 @@ int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_
     if (nchunk > 0) hipLaunchKernelGGL(moe_count_kernel, dim3(nchunk), dim3(256), 0, s, topk_ids, S, E, counts);
     hipLaunchKernelGGL(moe_place_kernel, dim3(nchunk > 0 ? nchunk : 1), dim3(256), 0, s, topk_ids, S, E, nbits, counts, nchunk, tile_m,
                        max_tiles, sorted_slot, expert_off, tile_info, num_tiles, tail_max > 0 ? tail_max : 0, tile_info_b, num_tiles_b,
-                       zero16, tail_any);
+                       zero16);
     SGLK_CHECK_LAUNCH("moe_align");
     return SGLK_OK;
 }
@@ -255,5 +253,5 @@ extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int
                               int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
                               void* workspace, size_t workspace_bytes, void* stream) {
     return sglk::launch_moe_align_split(topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles, 0, nullptr,
-                                        nullptr, workspace, workspace_bytes, stream, nullptr, 0);
+                                        nullptr, workspace, workspace_bytes, stream, nullptr);
 }

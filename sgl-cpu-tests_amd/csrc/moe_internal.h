@@ -80,11 +80,6 @@ struct A8GemmParams {
     uint8_t* out_s;               // GATE_UP: ic1 scale bytes [position][out_s_stride]
     int out_s_stride;
     const float* topk_weights;    // DOWN
-    // 128-token split kernel (moe_gemm_fp8w_s128.hip): tile_info holds the tiles of more than 96 rows, tile_info_b an expert's
-    // last tile of at most 96 rows; tickets = 9 zeroed counters (one per XCD for the first table, one for the second)
-    const int4* tile_info_b;
-    const int* num_tiles_b;
-    int* tickets;
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
 int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
@@ -95,7 +90,6 @@ int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, 
 // (moe_gemm_fp8w_s128.hip); tile table built with tile_m = 128; GATE_UP n_tiles = N / 128, DOWN n_tiles = K / 256
 int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
 bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n);
-bool moe_gemm_fp8w_s128_persistent();   // the experimental persistent form wants the two-table tile plan (tail_any)
 int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
                               int64_t rows, int cols, hipStream_t stream);
 // hidden bf16 [rows][cols] -> e4m3 (packed-tile k order) + one E8M0 byte per 128-wide block
@@ -304,7 +298,7 @@ int launch_gemm_mxfp4_native(const void* x, int64_t x_stride, const void* wq, co
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,
                            int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, int32_t tail_max,
                            int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream,
-                           int32_t* zero16 = nullptr, int tail_any = 0);   // zero16: 32 ints cleared by the same launches (tile tickets); tail_any: see moe_align.hip
+                           int32_t* zero16 = nullptr);   // zero16: 16 ints cleared by the same launches (tile tickets)
 
 // the routed experts' per-slot rows, to be summed (valid slots, ascending) and scaled inside another kernel's epilogue
 struct MoeSlotAddend {

@@ -88,43 +88,52 @@ def call(ops, q, a, tw, ids, inplace=False):
     return out
 
 
-@pytest.mark.parametrize("M", [4096, 16384])
+@pytest.mark.parametrize("M", [3929, 4096, 16384])
 def test_bench_size_against_oracle_and_launch_forms(ops, qwen3, knob, M):
-    """(a) every row computed on the GPU, >= 256 sampled tokens (every expert; full and tail tiles) against the C oracle;
-    (b) the default launch (GEMM-2 persistent with per-XCD tickets) == one workgroup per tile, bit for bit, and both ==
-    GEMM-1 persistent too; the 128-row kernel agrees within the stated bound."""
+    """(a) every row computed on the GPU, >= 256 sampled tokens (every expert; full and tail tiles) against the C oracle, on the
+    DEFAULT path: the two-term split on 128-token tiles, two workgroups per CU (moe_gemm_fp8w_s128.hip);
+    (b) the 256-row bf16-MFMA kernel (SGLK_S128=0): persistent / ticketed launch == one workgroup per tile, bit for bit, and
+    within the stated bound of the default; the 128-row bf16 kernel likewise.  M = 3929 is the reference bench's own batch
+    (/root/reference/bench_moe.py:145)."""
     from sgl_kernel import _lib, _ops
     a, tw, ids = routed_inputs(M, 100 + M)
     out = call(ops, qwen3, a, tw, ids)
     path = _ops.last_path
-    assert (path & _lib.PATH_TILE_MASK) == 256, f"bench sizes must run the 256-row kernel (path {path:#x})"
-    assert path & _lib.PATH_PERSIST_G2, "default GEMM-2 launch is the persistent one"
+    assert (path & _lib.PATH_TILE_MASK) == 128 and (path & _lib.PATH_SPLIT), f"bench sizes must run the 128-token split kernel (path {path:#x})"
     assert torch.isfinite(out.float()).all()
-    toks, fulls, tails, hit = sample_tokens(ids, E)
+    toks, fulls, tails, hit = sample_tokens(ids, E, tile=128)
     assert hit == E and len(toks) >= 256 and fulls >= E // 2 and tails > 0, (hit, len(toks), fulls, tails)
     ref = c_oracle.fused_experts_fp8(a[toks].cpu(), qwen3["w1"], qwen3["w2"], qwen3["w1s"].cpu(), qwen3["w2s"].cpu(), (BN, BK),
                                      tw[toks].cpu(), ids[toks].cpu())
     check_close(out[toks], ref, f"qwen3 M={M} ({len(toks)} sampled tokens)")
-
-    knob(SGLK_PERSIST=0)
-    out_np = call(ops, qwen3, a, tw, ids)
-    assert not (_ops.last_path & (_lib.PATH_PERSIST_G1 | _lib.PATH_PERSIST_G2))
-    assert torch.equal(out_np, out), "persistent / ticketed tile loop != one workgroup per tile"
-    knob(SGLK_PERSIST=1)
-    out_p = call(ops, qwen3, a, tw, ids)
-    assert (_ops.last_path & _lib.PATH_PERSIST_G1) and (_ops.last_path & _lib.PATH_PERSIST_G2)
-    assert torch.equal(out_p, out), "GEMM-1 persistent != one workgroup per tile"
+    assert torch.equal(call(ops, qwen3, a, tw, ids), out), "run-to-run bit identity"
     # inplace=True is the reference bench's call (bench_moe.py:113-130): same bits, written over hidden_states
-    knob(SGLK_PERSIST=None)
     a2 = a.clone()
     out_in = call(ops, qwen3, a2, tw, ids, inplace=True)
     assert out_in.data_ptr() == a2.data_ptr() and torch.equal(out_in, out)
-    # a different kernel (128-row tiles, two-stage pipeline): different rounding points, same stated bound
-    knob(SGLK_MOE_TILE_M=128, SGLK_TAIL_SPLIT=0)
+
+    # the 256-row bf16-MFMA kernel: other rounding points, same stated bound; its launch forms agree bit for bit
+    knob(SGLK_S128=0)
+    out256 = call(ops, qwen3, a, tw, ids)
+    path = _ops.last_path
+    assert (path & _lib.PATH_TILE_MASK) == 256 and not (path & _lib.PATH_SPLIT)
+    check_close(out256[toks], ref, f"qwen3 M={M}, 256-row bf16-MFMA kernel")
+    rel = (out256.float() - out.float()).norm() / out.float().norm()
+    assert rel < 3e-3, f"256-row bf16 kernel vs default: relative RMS {rel:.2e}"
+    knob(SGLK_PERSIST=0)
+    out_np = call(ops, qwen3, a, tw, ids)
+    assert not (_ops.last_path & (_lib.PATH_PERSIST_G1 | _lib.PATH_PERSIST_G2))
+    assert torch.equal(out_np, out256), "persistent / ticketed tile loop != one workgroup per tile"
+    knob(SGLK_PERSIST=1)
+    out_p = call(ops, qwen3, a, tw, ids)
+    assert (_ops.last_path & _lib.PATH_PERSIST_G1) and (_ops.last_path & _lib.PATH_PERSIST_G2)
+    assert torch.equal(out_p, out256), "GEMM-1 persistent != one workgroup per tile"
+    # a different kernel (128-row tiles, two-stage pipeline, bf16 MFMA): different rounding points, same stated bound
+    knob(SGLK_PERSIST=None, SGLK_MOE_TILE_M=128, SGLK_TAIL_SPLIT=0)
     out128 = call(ops, qwen3, a, tw, ids)
-    assert (_ops.last_path & _lib.PATH_TILE_MASK) == 128
+    assert (_ops.last_path & _lib.PATH_TILE_MASK) == 128 and not (_ops.last_path & _lib.PATH_SPLIT)
     rel = (out128.float() - out.float()).norm() / out.float().norm()
-    assert rel < 6e-3, f"128-row vs 256-row kernel: relative RMS {rel:.2e}"
+    assert rel < 6e-3, f"128-row bf16 kernel vs default: relative RMS {rel:.2e}"
 
 
 @pytest.mark.parametrize("name,cap", [("m1212_n512_k1024_e8_t2", 8), ("masked_m300_n256_k512_e16_t8", 4)])
