@@ -3,6 +3,7 @@
 #include "knobs.h"
 #include "moe_internal.h"
 #include "moe_align_inline.h"
+#include "fp8_split.h"
 
 #include <stdlib.h>
 
@@ -315,27 +316,44 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     // the sort costs what the launch did, hence 16 (SGLK_INLINE_ALIGN_MAX, 0 = off).
     const int inline_max = knobs().inline_align_max < kInlineAlignSlots ? knobs().inline_align_max : kInlineAlignSlots;
     const bool inline_align = tuned && !a8 && tile_m == kStreamTileM && !route && !split_tails && (int64_t)M * topk <= inline_max;
+    // the two-term split of `hidden` (W8A16 on the scaled fp8 MFMA) rides in moe_align's second launch as extra workgroups
+    const bool want_split = s128 || (tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
+                                     (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault));
+    SplitJob sjob{};
+    bool split_done = false;
+    if (want_split) {
+        sjob.x = (const uint16_t*)a->hidden;
+        sjob.x_stride = a->hidden_stride;
+        sjob.q = ws + w.xq;
+        sjob.q_stride = 2 * (int64_t)K;
+        sjob.s = ws + w.xs;
+        sjob.s_stride = (int64_t)align_up(K / 128, 4);
+        sjob.rows = M;
+        sjob.cols = K;
+    }
     if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
-                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets));
+                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), want_split ? &sjob : nullptr,
+                                    &split_done);
     if (rc != SGLK_OK) return rc;
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
     // 256-row regime: the two-term e4m3 split on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip) instead of the
     // bf16-MFMA kernel -- the same W8A16 contract (SGLK_SPLIT=0 / 1 overrides)
-    const bool split = s128 || (tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
-                                (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault));
+    const bool split = want_split;
     if (split) {
         uint8_t* xq = ws + w.xq;
         uint8_t* xs = ws + w.xs;
         uint8_t* ic1q = (uint8_t*)ic1;                 // split rows [position][2N] bytes: exactly the bf16 ic1's footprint
         uint8_t* ic1s = ws + w.ic1s;
         const int xs_stride = (int)align_up(K / 128, 4), ic1s_stride = (int)align_up(N / 128, 4);
-        rc = launch_split_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, 2 * (int64_t)K, xs, xs_stride, M, K, s);
-        if (rc != SGLK_OK) return rc;
-        mark(1);   // the split pass counts towards the align stage
+        if (!split_done) {   // (the one-launch align of small inputs has no second kernel to ride in)
+            rc = launch_split_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, 2 * (int64_t)K, xs, xs_stride, M, K, s);
+            if (rc != SGLK_OK) return rc;
+            mark(1);   // the split pass counts towards the align stage
+        }
         hipEvent_t ev_join = nullptr;
         if (split_tails) {   // the short tail tiles run on the weight-streaming bf16-MFMA kernel (their own rows of ic1 / ic2)
             const int tails_max = E < max_tiles ? E : max_tiles;
@@ -414,6 +432,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q1.out_stride = 2 * (int64_t)N;
         q1.out_s = ic1s;
         q1.out_s_stride = ic1s_stride;
+        q1.max_mtiles = max_tiles;
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
@@ -441,8 +460,9 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q2.out = ic2;
         q2.out_stride = K;
         q2.topk_weights = a->topk_weights;
+        q2.max_mtiles = max_tiles;
 #ifdef SGLK_DEV_ABLATE
-        if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
+        if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
 #endif
         rc = s128 ? launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s) : launch_moe_gemm_fp8w_split(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
@@ -509,7 +529,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q2.out_stride = K;
         q2.topk_weights = a->topk_weights;
 #ifdef SGLK_DEV_ABLATE
-        if (q1.dbg) q2.dbg = q1.dbg + 32 * 8192;
+        if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
 #endif
         rc = launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
@@ -623,7 +643,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g2.topk_weights = a->topk_weights;
         if (g1.tickets) g2.tickets = g1.tickets + 8;
 #ifdef SGLK_DEV_ABLATE
-        if (g1.dbg) g2.dbg = g1.dbg + 32 * 8192;
+        if (g1.dbg) g2.dbg = g1.dbg + 32 * 16384;
 #endif
         rc = tile_m == 256 ? launch_moe_gemm_fp8w_256i(MODE_DOWN, g2, max_tiles, s)
              : tile_m == kStreamTileM ? launch_moe_gemm_fp8w_stream(MODE_DOWN, g2, max_tiles, s)

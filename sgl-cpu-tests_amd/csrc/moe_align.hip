@@ -15,6 +15,7 @@
 //           chunk offset by the per-wave histograms.
 #include <stdlib.h>
 
+#include "fp8_split.h"
 #include "knobs.h"
 #include "moe_align_small.h"
 
@@ -50,7 +51,15 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
                                                         int* __restrict__ sorted_slot, int* __restrict__ expert_off,
                                                         int* __restrict__ tile_info, int* __restrict__ num_tiles, int tail_max,
                                                         int* __restrict__ tile_info_b, int* __restrict__ num_tiles_b,
-                                                        int* __restrict__ zero16) {
+                                                        int* __restrict__ zero16, const SplitJob job, int place_blocks) {
+    // workgroups past the placing ones split rows of `hidden` for the two-term W8A16 kernels (fp8_split.h): independent work
+    // that would otherwise be a launch of its own behind this one
+    if ((int)blockIdx.x >= place_blocks) {
+        const int64_t row = (int64_t)((int)blockIdx.x - place_blocks) * 4 + (threadIdx.x >> 6);
+        if (row < job.rows)
+            split_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);
+        return;
+    }
     __shared__ int s_tot[kMaxExperts];       // slots of the expert in the whole input
     __shared__ int s_base[kMaxExperts];      // slots of the expert in earlier chunks; after the scan: first position of MY chunk's
     __shared__ int s_run[4][kMaxExperts];    // per wave: slots of the expert placed so far by this chunk
@@ -218,7 +227,9 @@ namespace sglk {
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m,
                            int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
                            int32_t tail_max, int32_t* tile_info_b, int32_t* num_tiles_b,
-                           void* workspace, size_t workspace_bytes, void* stream, int32_t* zero16) {
+                           void* workspace, size_t workspace_bytes, void* stream, int32_t* zero16, const SplitJob* job,
+                           bool* job_taken) {
+    if (job_taken) *job_taken = false;
     SGLK_REQUIRE(M >= 0 && E > 0 && topk > 0 && tile_m > 0, SGLK_ERR_INVALID, "moe_align: bad sizes M=%d E=%d topk=%d", M, E, topk);
     SGLK_REQUIRE(E <= kMaxExperts, SGLK_ERR_SHAPE, "moe_align: at most %d experts supported (got %d)", kMaxExperts, E);
     SGLK_REQUIRE((int64_t)M * topk < (1ll << 31), SGLK_ERR_SHAPE, "moe_align: M*topk overflows int32");
@@ -241,9 +252,17 @@ int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_
         return SGLK_OK;
     }
     if (nchunk > 0) hipLaunchKernelGGL(moe_count_kernel, dim3(nchunk), dim3(256), 0, s, topk_ids, S, E, counts);
-    hipLaunchKernelGGL(moe_place_kernel, dim3(nchunk > 0 ? nchunk : 1), dim3(256), 0, s, topk_ids, S, E, nbits, counts, nchunk, tile_m,
+    const int place_blocks = nchunk > 0 ? nchunk : 1;
+    SplitJob j{};
+    int split_blocks = 0;
+    if (job && job->rows > 0) {
+        j = *job;
+        split_blocks = (int)ceil_div(job->rows, 4);
+        if (job_taken) *job_taken = true;
+    }
+    hipLaunchKernelGGL(moe_place_kernel, dim3(place_blocks + split_blocks), dim3(256), 0, s, topk_ids, S, E, nbits, counts, nchunk, tile_m,
                        max_tiles, sorted_slot, expert_off, tile_info, num_tiles, tail_max > 0 ? tail_max : 0, tile_info_b, num_tiles_b,
-                       zero16);
+                       zero16, j, place_blocks);
     SGLK_CHECK_LAUNCH("moe_align");
     return SGLK_OK;
 }
@@ -253,5 +272,5 @@ extern "C" int sglk_moe_align(const int32_t* topk_ids, int32_t M, int32_t E, int
                               int32_t* sorted_slot, int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles,
                               void* workspace, size_t workspace_bytes, void* stream) {
     return sglk::launch_moe_align_split(topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles, 0, nullptr,
-                                        nullptr, workspace, workspace_bytes, stream, nullptr);
+                                        nullptr, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }

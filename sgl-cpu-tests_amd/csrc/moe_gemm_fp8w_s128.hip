@@ -514,19 +514,21 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 template <int MODE, int NMOD, int ABL>
 __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
-    // XCD x owns the contiguous range [xs, xs + xl) of (m-tile, column tile) pairs, column tiles fastest: the column tiles of an
-    // m-tile share its gathered rows, the m-tiles of an expert its weights, both inside one L2
-    const int live = p.num_tiles[0] * p.n_tiles;
-    const int x = blockIdx.x & 7, q = live >> 3, r = live & 7;
-    const int xs = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-    const int xl = q + (x < r ? 1 : 0);
-    const int jt = blockIdx.x >> 3;
-    if (jt >= xl) return;
+    // Workgroup -> tile without knowing the tile count first (the table entry and the count are fetched side by side: one memory
+    // round trip less in every tile's prologue): the m-tiles are dealt to the 8 XCDs in groups of kGroup consecutive ones (about
+    // one expert's worth at the headline shape), column tiles fastest inside a group, so that the column tiles of an m-tile share
+    // its gathered rows and the m-tiles of an expert its weights inside one L2.  Workgroups past the last m-tile leave.
+    constexpr int kGroup = 8;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per = kGroup * p.n_tiles;
+    const int gi = j / per, rem = j - gi * per;
+    const int mi = rem / p.n_tiles;
+    const int mt = (gi * 8 + x) * kGroup + mi;
     TileId t;
-    t.L = xs + jt;
-    const int mt = t.L / p.n_tiles;
-    t.ntile = t.L - mt * p.n_tiles;
-    const int4 ti = p.tile_info[mt];
+    t.ntile = rem - mi * p.n_tiles;
+    t.L = mt * p.n_tiles + t.ntile;
+    const int4 ti = p.tile_info[mt < p.max_mtiles ? mt : 0];
+    if (mt >= p.num_tiles[0]) return;
     t.e = __builtin_amdgcn_readfirstlane(ti.x);
     t.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     t.rows = __builtin_amdgcn_readfirstlane(ti.z);
@@ -547,9 +549,11 @@ bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n) {
 }
 
 int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream) {
-    int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
-    if (blocks == 0) return SGLK_OK;
-    blocks = (blocks + 7) / 8 * 8;   // every XCD's share of the tile list must be reachable (blockIdx >> 3)
+    if ((int64_t)max_mtiles * p.n_tiles == 0) return SGLK_OK;
+    // groups of 8 m-tiles dealt round-robin to the 8 XCDs (see the kernel): every XCD gets the same number of workgroups
+    const int64_t groups = ceil_div(max_mtiles, 8), groups_per_xcd = ceil_div(groups, 8);
+    const int64_t blocks = groups_per_xcd * 8 * p.n_tiles * 8;
+    if (p.max_mtiles != max_mtiles) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: max_mtiles not set in the parameter block");
     const int kblocks = p.C >> 7;
     if (p.C % 128 != 0 || kblocks < 2 || kblocks > gs128::kMaxKB)
         SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: reduction length %d (needs 2..%d whole 128-wide K blocks)", p.C, gs128::kMaxKB);

@@ -28,55 +28,15 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // ------------------------------------------------------------------------------------------------------------------------
 // hidden [rows][cols] bf16 -> q [rows][2 * cols] ([hi 64 | lo 64] per 64 group, packed-tile k order) + one E8M0 byte per
-// 128-wide block.  One wave per row, 2048 columns per pass (lane = 32 consecutive columns, 4 lanes = one block).
+// 128-wide block.  One wave per row (fp8_split.h: split_row_block128).
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void split_fp8_block128_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                                  uint8_t* __restrict__ q, int64_t q_stride,
                                                                  uint8_t* __restrict__ s, int64_t s_stride, int64_t rows,
                                                                  int cols) {
-    const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const uint16_t* xr = x + row * x_stride;
-    uint8_t* qr = q + row * q_stride;
-    for (int c0 = 0; c0 < cols; c0 += 2048) {
-        const int c = c0 + lane * 32;
-        const bool live = c < cols;
-        float v[32];
-        float amax = 0.f;
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint4 w4 = *reinterpret_cast<const uint4*>(xr + c + j * 8);
-                const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[j * 8 + 2 * i] = __uint_as_float(w[i] << 16);
-                    v[j * 8 + 2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = 0.f;
-        }
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
-        const int sb = sp_e8m0_for_amax(amax);
-        if (live) {
-            if ((lane & 3) == 0) s[row * s_stride + (c >> 7)] = (uint8_t)sb;
-            // the lane holds k = 32 hi + j (hi = lane & 1) of its 64 group; run (j0 = 0, 8, 16, 24) -> position 8 hi + {0, 16, 32, 48}
-            uint8_t* g64 = qr + 2 * (c & ~63) + 8 * (lane & 1);
-#pragma unroll
-            for (int run = 0; run < 4; ++run) {
-                unsigned hi[2], lo[2];
-                split8(v + run * 8, sb, hi, lo);
-                *reinterpret_cast<uint2*>(g64 + run * 16) = make_uint2(hi[0], hi[1]);
-                *reinterpret_cast<uint2*>(g64 + 64 + run * 16) = make_uint2(lo[0], lo[1]);
-            }
-        }
-    }
+    split_row_block128(x + row * x_stride, q + row * q_stride, s + row * s_stride, cols, threadIdx.x & 63);
 }
 
 int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,

@@ -80,6 +80,7 @@ struct A8GemmParams {
     uint8_t* out_s;               // GATE_UP: ic1 scale bytes [position][out_s_stride]
     int out_s_stride;
     const float* topk_weights;    // DOWN
+    int max_mtiles;               // s128 kernel: entries of tile_info that may be read (the launch's m-tile bound)
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
 int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
@@ -298,7 +299,10 @@ int launch_gemm_mxfp4_native(const void* x, int64_t x_stride, const void* wq, co
 int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_t topk, int32_t tile_m, int32_t* sorted_slot,
                            int32_t* expert_off, int32_t* tile_info, int32_t* num_tiles, int32_t tail_max,
                            int32_t* tile_info_b, int32_t* num_tiles_b, void* workspace, size_t workspace_bytes, void* stream,
-                           int32_t* zero16 = nullptr);   // zero16: 16 ints cleared by the same launches (tile tickets)
+                           int32_t* zero16 = nullptr,   // zero16: 16 ints cleared by the same launches (tile tickets)
+                           const struct SplitJob* job = nullptr, bool* job_taken = nullptr);   // job: rows of `hidden` split by extra
+                                                                                               // workgroups of the placing launch (fp8_split.h);
+                                                                                               // *job_taken = false: the caller launches it
 
 // the routed experts' per-slot rows, to be summed (valid slots, ascending) and scaled inside another kernel's epilogue
 struct MoeSlotAddend {

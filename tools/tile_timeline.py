@@ -17,7 +17,7 @@ w1s = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3
 w2s = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
 a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
 tw, ids = torch.topk(torch.softmax(torch.randn(M, E, device="cuda", generator=g), dim=-1), topk); ids = ids.to(torch.int32)
-dbg = torch.zeros(2 * 32 * 8192, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(2 * 32 * 16384, dtype=torch.int64, device="cuda")
 os.environ["SGLK_DBG_PTR"] = hex(dbg.data_ptr())
 f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
 t0 = time.time()
