@@ -5,6 +5,18 @@
 
 namespace sglk {
 
+// E8M0 byte of the power-of-two scale of a 128-wide block with largest magnitude `amax` (>= 0): the smallest 2^e with
+// amax / 2^e <= 448 = 1.75 * 2^8 (e4m3's largest finite value), clamped to [1, 253].  Integer arithmetic on the float's
+// bits, so the oracle (oracle/moe_a8.py: e8m0_for_amax) reproduces it exactly.
+SGLK_DEV int e8m0_for_amax(float amax) {
+    const unsigned u = __float_as_uint(amax);
+    int sb = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
+    sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
+    return sb;
+}
+SGLK_DEV float inv_scale_of(int sb) { return __uint_as_float((unsigned)(254 - sb) << 23); }   // 2^(127 - sb), exact
+
+
 SGLK_DEV int sp_e8m0_for_amax(float amax) {   // as e8m0_for_amax of moe_gemm_a8.hip, floor 5 so that the lo scale (sb - 4) >= 1
     const unsigned u = __float_as_uint(amax);
     int sb = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
@@ -81,6 +93,49 @@ SGLK_DEV void split_row_block128(const uint16_t* __restrict__ xr, uint8_t* __res
     }
 }
 
+// The a8 mode's quantiser for one row, same lane mapping: q = 64 e4m3 bytes per 64-wide k group in the packed weight tile's k
+// order, the smallest power-of-two scale with amax / 2^e <= 448 per 128-wide block (e8m0_for_amax: floor 1, not 5)
+SGLK_DEV void quant_row_block128(const uint16_t* __restrict__ xr, uint8_t* __restrict__ qr, uint8_t* __restrict__ sr, int cols,
+                                 int lane) {
+    for (int c0 = 0; c0 < cols; c0 += 1024) {
+        const int g = lane >> 2, o = lane & 3;
+        const int c = c0 + g * 64;
+        const bool live = c < cols;
+        float v[16];
+        float amax = 0.f;
+        if (live) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(xr + c + 8 * o);
+            const uint4 b4 = *reinterpret_cast<const uint4*>(xr + c + 32 + 8 * o);
+            const unsigned w[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[2 * i] = __uint_as_float(w[i] << 16);
+                v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(v[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = 0.f;
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, __shfl_xor(amax, 4));
+        const int sb = e8m0_for_amax(amax);
+        const float inv = inv_scale_of(sb);
+        if (live) {
+            if ((lane & 7) == 0) sr[c >> 7] = (uint8_t)sb;
+            int d[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 0] * inv, v[4 * i + 1] * inv, d[i], false);
+                d[i] = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * i + 2] * inv, v[4 * i + 3] * inv, d[i], true);
+            }
+            *reinterpret_cast<uint4*>(qr + c + 16 * o) = make_uint4((unsigned)d[0], (unsigned)d[1], (unsigned)d[2], (unsigned)d[3]);
+        }
+    }
+}
+
 // the split of `hidden` as extra workgroups of another launch (moe_align's second kernel: the two are independent and
 // together shorter than back to back)
 struct SplitJob {
@@ -92,6 +147,7 @@ struct SplitJob {
     int64_t s_stride;       // bytes
     int64_t rows;
     int cols;
+    int terms;              // 2: the two-term split (q rows of 2 * cols bytes); 1: the a8 mode's quantised rows (cols bytes)
 };
 
 }  // namespace sglk

@@ -14,7 +14,9 @@ using namespace sglk;
 namespace {
 
 constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
-constexpr bool kS128Default = true;     // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
+constexpr bool kS128Default = true;
+constexpr bool kA8S128Default = true;   // the opt-in a8 mode on the 128-token kernel when SGLK_A8_S128 is unset
+    // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
 
 struct StageTimer {
     int max_calls = 0, calls = 0;
@@ -279,6 +281,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     const bool s128 = tuned && !a8 && tile_m == 256 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (int64_t)M * K * 2 < (1ll << 32) &&
                       (int64_t)M * topk * N * 2 < (1ll << 32) && s128_on;
     if (s128) tile_m = 128;
+    const bool a8s = a8 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (knobs().a8_s128 >= 0 ? knobs().a8_s128 == 1 : kA8S128Default);
+    if (a8s) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -330,11 +334,23 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         sjob.s_stride = (int64_t)align_up(K / 128, 4);
         sjob.rows = M;
         sjob.cols = K;
+        sjob.terms = 2;
+    }
+    if (a8) {   // the a8 mode's quantisation pass rides the same way
+        sjob.x = (const uint16_t*)a->hidden;
+        sjob.x_stride = a->hidden_stride;
+        sjob.q = ws + w.xq;
+        sjob.q_stride = K;
+        sjob.s = ws + w.xs;
+        sjob.s_stride = (int64_t)align_up(K / 128, 4);
+        sjob.rows = M;
+        sjob.cols = K;
+        sjob.terms = 1;
     }
     if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
-                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), want_split ? &sjob : nullptr,
+                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), (want_split || a8) ? &sjob : nullptr,
                                     &split_done);
     if (rc != SGLK_OK) return rc;
     mark(1);
@@ -475,9 +491,11 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         uint8_t* ic1q = ws + w.ic1q;
         uint8_t* ic1s = ws + w.ic1s;
         const int xs_stride = (int)align_up(K / 128, 4), ic1s_stride = (int)align_up(N / 128, 4);
-        rc = launch_quant_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, xs_stride, M, K, s);
-        if (rc != SGLK_OK) return rc;
-        mark(1);   // the quantisation pass counts towards the align stage
+        if (!split_done) {
+            rc = launch_quant_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, xs_stride, M, K, s);
+            if (rc != SGLK_OK) return rc;
+            mark(1);   // the quantisation pass counts towards the align stage
+        }
         A8GemmParams q1{};
         q1.x = xq;
         q1.x_stride = K;
@@ -504,7 +522,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
-        rc = launch_moe_gemm_a8(MODE_GATE_UP, q1, max_tiles, s);
+        q1.max_mtiles = max_tiles;
+        rc = a8s ? launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s, 1) : launch_moe_gemm_a8(MODE_GATE_UP, q1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
         A8GemmParams q2{};
@@ -531,7 +550,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
 #endif
-        rc = launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
+        q2.max_mtiles = max_tiles;
+        rc = a8s ? launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s, 1) : launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else if (tuned) {

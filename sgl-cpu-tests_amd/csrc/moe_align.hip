@@ -56,8 +56,12 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
     // that would otherwise be a launch of its own behind this one
     if ((int)blockIdx.x >= place_blocks) {
         const int64_t row = (int64_t)((int)blockIdx.x - place_blocks) * 4 + (threadIdx.x >> 6);
-        if (row < job.rows)
-            split_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);
+        if (row < job.rows) {
+            if (job.terms == 2)
+                split_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);
+            else
+                quant_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);
+        }
         return;
     }
     __shared__ int s_tot[kMaxExperts];       // slots of the expert in the whole input

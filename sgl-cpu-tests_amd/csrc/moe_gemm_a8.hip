@@ -17,6 +17,7 @@
 //     operand), K in 64-deep stages (= ONE MFMA k-step) through a ring of FOUR 32-KiB LDS buffers filled by LDS-DMA three
 //     stages ahead; one counted vmcnt + one barrier per stage; the operand fragments of stage t+1 are read during the MFMAs
 //     of stage t.
+#include "fp8_split.h"
 #include "knobs.h"
 #include "moe_internal.h"
 
@@ -54,77 +55,23 @@ SGLK_DEV void split_scale(float s_in, int& eb, float& mant) {
 
 }  // namespace ga8
 
-// E8M0 byte of the power-of-two scale of a 128-wide block with largest magnitude `amax` (>= 0): the smallest 2^e with
-// amax / 2^e <= 448 = 1.75 * 2^8 (e4m3's largest finite value), clamped to [1, 253].  Integer arithmetic on the float's
-// bits, so the oracle (oracle/moe_a8.py: e8m0_for_amax) reproduces it exactly.
-SGLK_DEV int e8m0_for_amax(float amax) {
-    const unsigned u = __float_as_uint(amax);
-    int sb = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
-    sb = sb < 1 ? 1 : (sb > 253 ? 253 : sb);
-    return sb;
-}
-SGLK_DEV float inv_scale_of(int sb) { return __uint_as_float((unsigned)(254 - sb) << 23); }   // 2^(127 - sb), exact
-
 // ------------------------------------------------------------------------------------------------------------------------
 // hidden [rows][cols] bf16 -> q [rows][cols] e4m3 (k order of the packed weight tile inside every 64 group) + one E8M0 byte
-// per 128-wide block.  One wave per row, 2048 columns per pass (lane = 32 consecutive columns, 4 lanes = one block).
+// per 128-wide block.  One wave per row (fp8_split.h: quant_row_block128).
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quant_fp8_block128_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                                  uint8_t* __restrict__ q, int64_t q_stride,
                                                                  uint8_t* __restrict__ s, int64_t s_stride, int64_t rows,
                                                                  int cols) {
-    const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const uint16_t* xr = x + row * x_stride;
-    uint8_t* qr = q + row * q_stride;
-    for (int c0 = 0; c0 < cols; c0 += 2048) {
-        const int c = c0 + lane * 32;
-        const bool live = c < cols;
-        float v[32];
-        float amax = 0.f;
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint4 w4 = *reinterpret_cast<const uint4*>(xr + c + j * 8);
-                const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[j * 8 + 2 * i] = __uint_as_float(w[i] << 16);
-                    v[j * 8 + 2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 32; ++j) amax = fmaxf(amax, fabsf(v[j]));
-        } else {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) v[j] = 0.f;
-        }
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
-        const int sb = e8m0_for_amax(amax);
-        const float inv = inv_scale_of(sb);
-        if (live) {
-            if ((lane & 3) == 0) s[row * s_stride + (c >> 7)] = (uint8_t)sb;
-            // the lane holds k = 32 hi + j (hi = lane & 1) of its 64 group; run (j0 = 0, 8, 16, 24) -> position 8 hi + {0, 16, 32, 48}
-            uint8_t* g64 = qr + (c & ~63) + 8 * (lane & 1);
-#pragma unroll
-            for (int run = 0; run < 4; ++run) {
-                int lo = 0, hi2 = 0;
-                lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[run * 8 + 0] * inv, v[run * 8 + 1] * inv, lo, false);
-                lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[run * 8 + 2] * inv, v[run * 8 + 3] * inv, lo, true);
-                hi2 = __builtin_amdgcn_cvt_pk_fp8_f32(v[run * 8 + 4] * inv, v[run * 8 + 5] * inv, hi2, false);
-                hi2 = __builtin_amdgcn_cvt_pk_fp8_f32(v[run * 8 + 6] * inv, v[run * 8 + 7] * inv, hi2, true);
-                *reinterpret_cast<uint2*>(g64 + run * 16) = make_uint2((unsigned)lo, (unsigned)hi2);
-            }
-        }
-    }
+    quant_row_block128(x + row * x_stride, q + row * q_stride, s + row * s_stride, cols, threadIdx.x & 63);
 }
 
 int launch_quant_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
                               int64_t rows, int cols, hipStream_t stream) {
     if (rows == 0) return SGLK_OK;
-    if (cols % 128 != 0 || x_stride % 8 != 0 || ((uintptr_t)x % 16) != 0 || q_stride % 8 != 0 || ((uintptr_t)q % 8) != 0)
+    if (cols % 128 != 0 || x_stride % 8 != 0 || ((uintptr_t)x % 16) != 0 || q_stride % 16 != 0 || ((uintptr_t)q % 16) != 0)
         SGLK_FAIL(SGLK_ERR_SHAPE, "quant_fp8_block128: %d columns / strides / alignment not supported", cols);
     hipLaunchKernelGGL(quant_fp8_block128_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, stream, x, x_stride, q, q_stride,
                        s, s_stride, rows, cols);

@@ -79,8 +79,15 @@ struct TileId {
 // NTA = token tiles (32 tokens) of the tile that hold at least one row: 4 for full tiles, 1..3 for an expert's last tile, which
 // skips the fragment reads, MFMAs and rescales of the token tiles without rows.  The whole tile is compiled per count (a
 // run-time test in front of every MFMA, or a switch around the main loop alone, cost the register allocator 30-100 spills).
-template <int MODE, int NMOD, int ABL, int NTA>
+// TERMS = e4m3 terms per activation: 2 = the exact two-term split of the bf16 value (W8A16, the reference's numerics); 1 = the
+// opt-in a8 mode (activations QUANTISED to e4m3 per token x 128 block: moe_gemm_a8.hip's formats and oracle, half the MFMAs,
+// X bytes and LDS reads per stage).
+template <int MODE, int NMOD, int ABL, int NTA, int TERMS>
 SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId cur) {
+    constexpr int kXB = 64 * TERMS;             // activation bytes per token and stage
+    constexpr int kStageXT = kBM * kXB;         // ring slot: 16 KiB (two terms) / 8 KiB
+    constexpr int kXP = 2 * TERMS;              // 1-KiB LDS-DMA pieces of a stage per wave
+    constexpr int kSP = 8 * TERMS;              // MFMAs of a stage per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,9 +123,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     }
     // B (tokens), token tile tt: row = tt * 32 + r32; hi chunks 2h, 2h + 1, lo chunks 4 + 2h, 5 + 2h, each ^ ((row >> 1) & 7),
     // which only depends on r32; token tile tt is + tt * 4096 bytes (an immediate)
-    const int sw = (r32 >> 1) & 7;
-    const int xo_h0 = r32 * 128 + (((2 * h) ^ sw) << 4), xo_h1 = r32 * 128 + (((2 * h + 1) ^ sw) << 4);
-    const int xo_l0 = r32 * 128 + (((4 + 2 * h) ^ sw) << 4), xo_l1 = r32 * 128 + (((5 + 2 * h) ^ sw) << 4);
+    // (one term: rows of 64 bytes, chunks 2h, 2h + 1 ^ ((row >> 2) & 3), token tile tt + tt * 2048)
+    const int sw = TERMS == 2 ? (r32 >> 1) & 7 : (r32 >> 2) & 3;
+    const int xo_h0 = r32 * kXB + (((2 * h) ^ sw) << 4), xo_h1 = r32 * kXB + (((2 * h + 1) ^ sw) << 4);
+    const int xo_l0 = r32 * kXB + (((4 + 2 * h) ^ sw) << 4), xo_l1 = r32 * kXB + (((5 + 2 * h) ^ sw) << 4);   // two terms only
 
     // ---- prologue loads (parked in registers; written to the LDS tables after the first operand loads have been issued) ----
     float sc_reg[2];
@@ -158,16 +166,18 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (int64_t)cur.e * p.w_expert_stride), 0,
                                                                            (unsigned)p.w_expert_stride, 0x00020000);
-    unsigned xsrc[4], wsrc[2];
+    unsigned xsrc[kXP], wsrc[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wn * 4 + i) * 8 + (lane >> 3);
+    for (int i = 0; i < kXP; ++i) {
+        // a piece = 1 KiB = 8 rows x 128 B (two terms) or 16 rows x 64 B
+        const int r = TERMS == 2 ? (wn * 4 + i) * 8 + (lane >> 3) : (wn * 2 + i) * 16 + (lane >> 2);
         unsigned off = xbytes;
         if (r < cur.rows) {
             int64_t xrow;
             if (MODE == MODE_GATE_UP) xrow = (int64_t)(p.sorted_slot[cur.pos0 + r] / p.topk);
             else xrow = (int64_t)(cur.pos0 + r);
-            off = (unsigned)(xrow * p.x_stride) + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) << 4);
+            const unsigned chunk = TERMS == 2 ? (unsigned)((lane & 7) ^ ((r >> 1) & 7)) : (unsigned)((lane & 3) ^ ((r >> 2) & 3));
+            off = (unsigned)(xrow * p.x_stride) + (chunk << 4);
         }
         xsrc[i] = off;
     }
@@ -175,7 +185,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     for (int rt = 0; rt < 2; ++rt)
         wsrc[rt] = (unsigned)(piece_row16(wpiece0[rt] + (r32 >> 4)) * ctiles) * 1024u + (unsigned)(((2 * h) * 16 + (r32 & 15)) * 16);
     auto issue_x = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // piece i (0..3) of this wave, stage kt
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_s1_t)(smem + buf * kStageX + (wn * 4 + i) * 1024), 16, xsrc[i], kt * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_s1_t)(smem + buf * kStageXT + (wn * kXP + i) * 1024), 16, xsrc[i], kt * kXB, 0, 0);
     };
     i32x8 fa[3][2] = {};                   // [(stage + const) % 3][row tile]
     auto ld_a = [&](int as, int rt, int kt) __attribute__((always_inline)) {
@@ -189,13 +199,13 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_x(st, st, i);
+        for (int i = 0; i < kXP; ++i) issue_x(st, st, i);
         ld_a((kSet0 + st) % 3, 0, st);
         ld_a((kSet0 + st) % 3, 1, st);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_x(2, 2, i);
-    issue_x(3, 3, 0);   // pieces 2, 3 of X(3) are carried into stage 0 like every later stage's
+    for (int i = 0; i < kXP; ++i) issue_x(2, 2, i);
+    issue_x(3, 3, 0);   // two terms: pieces 2, 3 of X(3) are carried into stage 0 like every later stage's
     issue_x(3, 3, 1);
     sc[tid] = sc_reg[0];
     sc[tid + 256] = sc_reg[1];
@@ -208,7 +218,9 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             }
         if (MODE == MODE_DOWN) slot_tab[tid] = my_slot;
     }
-    __builtin_amdgcn_s_waitcnt(wc(14, 0));   // X(0) and A(0) have landed; X(1) A(1) X(2) + two pieces of X(3) = 14 operations stay in flight
+    // X(0) and A(0) have landed; X(1) A(1) X(2) + two pieces of X(3) = 14 (two terms) / 10 operations stay in flight
+    if (TERMS == 2) __builtin_amdgcn_s_waitcnt(wc(14, 0));
+    else __builtin_amdgcn_s_waitcnt(wc(10, 0));
     __builtin_amdgcn_s_barrier();
 
     f32x16 acc[2][4];
@@ -240,25 +252,35 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     // four MFMAs ahead, measured the same: 0.6637 vs 0.6600 ms.)
     // ABL (developer builds, wrong results by design): 1 = no accumulator rescale, 2 = no activation DMA in the steady state,
     // 4 = no weight loads in the steady state
-    i32x8 bh = {}, bl = {};
+    // One term: two windows of hi fragments, set tt & 1 for token tile tt, the next tile's requested behind the first of the
+    // current tile's two MFMAs.
+    i32x8 bh = {}, bl = {};     // two terms: hi / lo window; one term: windows 0 / 1
     float nsc[2] = {0.f, 0.f};
     auto ld_bh = [&](int tt, int buf) __attribute__((always_inline)) {
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_h0) + tt * 4096);
-        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_h1) + tt * 4096);
-        bh = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageXT + xo_h0) + tt * (32 * kXB));
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageXT + xo_h1) + tt * (32 * kXB));
+        const i32x8 f = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (TERMS == 2 || (tt & 1) == 0) bh = f;
+        else bl = f;
     };
-    auto ld_bl = [&](int tt, int buf) __attribute__((always_inline)) {
-        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_l0) + tt * 4096);
-        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageX + xo_l1) + tt * 4096);
+    auto ld_bl = [&](int tt, int buf) __attribute__((always_inline)) {   // two terms only
+        const i32x4 a0 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageXT + xo_l0) + tt * 4096);
+        const i32x4 a1 = *reinterpret_cast<const i32x4*>(smem + (buf * kStageXT + xo_l1) + tt * 4096);
         bl = i32x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
     };
-    // MFMA slot s of a stage (16 per wave): token tile s >> 2, then hi x rt0, hi x rt1, lo x rt0, lo x rt1
+    // MFMA slot s of a stage.  Two terms (16 per wave): token tile s >> 2, then hi x rt0, hi x rt1, lo x rt0, lo x rt1; one term
+    // (8): token tile s >> 1, then rt0, rt1
     auto mma = [&](int as, int s2) __attribute__((always_inline)) {
-        const int tt = s2 >> 2, lo = (s2 >> 1) & 1, rt = s2 & 1;
-        if (lo)
-            acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bl, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt] - 4);
-        else
-            acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bh, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
+        if (TERMS == 2) {
+            const int tt = s2 >> 2, lo = (s2 >> 1) & 1, rt = s2 & 1;
+            if (lo)
+                acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bl, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt] - 4);
+            else
+                acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bh, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
+        } else {
+            const int tt = s2 >> 1, rt = s2 & 1;
+            acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], (tt & 1) ? bl : bh, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
+        }
     };
     // accumulator tile (rt, tt) into units of the next K block's mantissa, four registers (chunk c) at a time: a wave that has
     // its SIMD to itself is issue-bound, so the 128 multiplies of a K-block boundary are spread four per tile and MFMA slot
@@ -267,15 +289,15 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][c * 4 + i]) : "s"(ratio[rt]));
     };
-    // chunks due behind MFMA slot g (0 .. 31 over the closing stage and the first stage of the next block): tile (rt, tt) is
-    // free from slot 4 tt + 3 + rt of the closing stage (its last MFMA of the block was slot 4 tt + 2 + rt) until its first
-    // MFMA of the next block, slot 16 + 4 tt + rt; chunk c goes behind slot 4 tt + 3 + rt + c
+    // chunks due behind MFMA slot g (0 .. 2 kSP - 1 over the closing stage and the first stage of the next block): tile (rt, tt)
+    // is free behind its last MFMA of the block (two terms: slot 4 tt + 2 + rt; one: 2 tt + rt) until its first MFMA of the
+    // next block; chunk c goes behind the slot c places after that last MFMA
     auto rescale_slot = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int tt = 0; tt < NTA; ++tt)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-                const int c = g - (4 * tt + 3 + rt);
+                const int c = g - ((TERMS == 2 ? 4 * tt + 2 : 2 * tt) + rt + 1);
                 if (c >= 0 && c < 4) rescale4(rt, tt, c);
             }
     };
@@ -291,10 +313,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     //   bound  : closing stage of a K block that is not the last -- rescale chunks, and the next block's activation scale bytes
     //            are read (behind each token tile's last MFMA)
     //   lda    : stage t+2 exists: its weight fragments are requested (slots 0, 4) into fa[(as + 2) % 3], dead since stage t-1
-    //   wait   : >= 0: stage t+1 exists; sync point after slot 13 = s_waitcnt vmcnt(wait) (X(t+1) and A(t+1) have landed; the nine
-    //            operations issued behind them -- the last piece of X(t+2), half of X(t+3), A(t+2), the rest of X(t+3) -- may
-    //            stay in flight; the literals 9 / 5 / 0 come from replaying the issue order, tools/s128_waits.py) + lgkmcnt(0)
-    //            + barrier.  Every fragment of THIS stage has been read by then, so afterwards X(t+4) goes into this stage's
+    //   wait   : >= 0: stage t+1 exists; sync point = s_waitcnt vmcnt(N) (X(t+1) and A(t+1) have landed; the operations issued
+    //            behind them -- two terms: the last piece of X(t+2), half of X(t+3), A(t+2), the rest of X(t+3) -- may stay in
+    //            flight; N = 9 / 5 / 0 (two terms), 6 / 4 / 0 (one) for wait = 2 (steady) / 1 (stage T-3) / 0 (stage T-2), from
+    //            replaying the issue order: tools/s128_waits.py) + lgkmcnt(0) + barrier.  Every fragment of THIS stage has been read by then, so afterwards X(t+4) goes into this stage's
     //            ring slot and the first fragments of stage t+1 are read
     //   dmax   : stage t+4 exists: pieces 0, 1 of X(t+4) go out behind slots 14, 15 (one LDS-DMA per slot: a piece costs the
     //            issuing wave 60-180 cycles, more than one MFMA's shadow), pieces 2, 3 are carried into stage t+1
@@ -322,30 +344,33 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             }
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            const int tt = s2 >> 2, q = s2 & 3;
+        for (int s2 = 0; s2 < kSP; ++s2) {
+            const int tt = TERMS == 2 ? s2 >> 2 : s2 >> 1, q = TERMS == 2 ? s2 & 3 : s2 & 1;
             if (tt < NTA) mma(as, s2);
             SGLK_FENCE();
-            // the hi fragment is free after the tile's second MFMA, the lo fragment after its fourth
-            if (q == 1 && tt + 1 < NTA) ld_bh(tt + 1, buf);
-            if (q == 3 && tt + 1 < NTA) ld_bl(tt + 1, buf);
-            if (q == 3 && bound && tt < NTA) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
+            if (TERMS == 2) {   // the hi fragment is free after the tile's second MFMA, the lo fragment after its fourth
+                if (q == 1 && tt + 1 < NTA) ld_bh(tt + 1, buf);
+                if (q == 3 && tt + 1 < NTA) ld_bl(tt + 1, buf);
+            } else {            // the other window has been free since the previous tile's second MFMA
+                if (q == 0 && tt + 1 < NTA) ld_bh(tt + 1, buf);
+            }
+            if (q == kSP / 4 - 1 && bound && tt < NTA) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
             if (s2 == 0 && lda && !(ABL & 4)) ld_a(as2, 0, t + 2);
-            if (s2 == 4 && lda && !(ABL & 4)) ld_a(as2, 1, t + 2);
-            if (s2 == 2 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 2);
-            if (s2 == 6 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 3);
+            if (s2 == kSP / 4 && lda && !(ABL & 4)) ld_a(as2, 1, t + 2);
+            if (TERMS == 2 && s2 == 2 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 2);
+            if (TERMS == 2 && s2 == 6 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 3);
             if (bound) rescale_slot(s2);
-            if (first) rescale_slot(16 + s2);
-            if (s2 == 13 && wait >= 0) {
-                if (wait == 9) __builtin_amdgcn_s_waitcnt(wc(9, 0));
-                else if (wait == 5) __builtin_amdgcn_s_waitcnt(wc(5, 0));
+            if (first) rescale_slot(kSP + s2);
+            if (s2 == kSP - 3 + (TERMS == 1) && wait >= 0) {   // behind slot 13 (two terms) / 6: every fragment of this stage has been read
+                if (wait == 2) __builtin_amdgcn_s_waitcnt(wc(TERMS == 2 ? 9 : 6, 0));
+                else if (wait == 1) __builtin_amdgcn_s_waitcnt(wc(TERMS == 2 ? 5 : 4, 0));
                 else __builtin_amdgcn_s_waitcnt(wc(0, 0));
                 __builtin_amdgcn_s_barrier();
                 ld_bh(0, nbuf);
             }
-            if (s2 == 14 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 0);
-            if (s2 == 15 && wait >= 0) ld_bl(0, nbuf);
-            if (s2 == 15 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 1);
+            if (s2 == kSP - 2 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 0);
+            if (TERMS == 2 && s2 == 15 && wait >= 0) ld_bl(0, nbuf);
+            if (s2 == kSP - 1 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 1);
             SGLK_FENCE();
         }
         buf = nbuf;
@@ -357,11 +382,11 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     auto kblock = [&](int ph, int kind, int kb) __attribute__((always_inline)) {
         const int t = 2 * kb, a0 = (2 * ph) % 3, a1 = (2 * ph + 1) % 3;
         if (kind == KB_STEADY) {
-            stage(a0, t, true, false, 9, true, true, true, true);
-            stage(a1, t + 1, false, true, 9, true, true, false, true);
+            stage(a0, t, true, false, 2, true, true, true, true);
+            stage(a1, t + 1, false, true, 2, true, true, false, true);
         } else if (kind == KB_PENULT) {
-            stage(a0, t, true, false, 9, false, true, true, true);
-            stage(a1, t + 1, false, true, 5, false, true, false, false);
+            stage(a0, t, true, false, 2, false, true, true, true);
+            stage(a1, t + 1, false, true, 1, false, true, false, false);
         } else {
             if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];   // covered by stage T-2's vmcnt(0)
             stage(a0, t, true, false, 0, false, false, false, false);
@@ -370,7 +395,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     };
     {
         ld_bh(0, 0);
-        ld_bl(0, 0);
+        if (TERMS == 2) ld_bl(0, 0);
         SGLK_FENCE();
         int kb = 0;
         if (NMOD == 2) kblock(2, KB_STEADY, kb++);
@@ -400,7 +425,56 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     int tidv = tid;
     asm volatile("" : "+v"(tidv));
     const int r32e = tidv & 31, he = (tidv >> 5) & 1;
-    if (MODE == MODE_GATE_UP) {
+    if (MODE == MODE_GATE_UP && TERMS == 1) {
+        // a8: ic1 = silu(gate) * up for this workgroup's 128 columns = ONE K block of GEMM-2, quantised like `hidden`: per-token
+        // amax over the four waves, power-of-two scale, e4m3, stored in the packed-tile k order (moe_gemm_a8.hip's formats)
+        float v[4][16];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            float am = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float g = acc[0][tt][i] * mant[0], u = acc[1][tt][i] * mant[1];
+                v[tt][i] = silu_f32(g) * u;
+                am = fmaxf(am, fabsf(v[tt][i]));
+            }
+            am = fmaxf(am, __shfl_xor(am, 32));
+            if (he == 0) amax_tab[wn * kBM + tt * 32 + r32e] = am;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int r = tt * 32 + r32e;
+            const float am = fmaxf(fmaxf(amax_tab[r], amax_tab[kBM + r]), fmaxf(amax_tab[2 * kBM + r], amax_tab[3 * kBM + r]));
+            const int sb = e8m0_for_amax(am);
+            const float inv = inv_scale_of(sb);
+            if (wn == 0 && he == 0 && r < cur.rows) p.out_s[(int64_t)(cur.pos0 + r) * p.out_s_stride + cur.ntile] = (uint8_t)sb;
+            unsigned char* rowp = smem + r * 128;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                int d = 0;
+                d = __builtin_amdgcn_cvt_pk_fp8_f32(v[tt][rg * 4 + 0] * inv, v[tt][rg * 4 + 1] * inv, d, false);
+                d = __builtin_amdgcn_cvt_pk_fp8_f32(v[tt][rg * 4 + 2] * inv, v[tt][rg * 4 + 3] * inv, d, true);
+                // columns wn*32 + rg*8 + he*4 .. +3 of the 128: 64 group wn >> 1, k = (wn & 1)*32 + rg*8 + he*4
+                //   -> position 32*(rg >> 1) + 8*(wn & 1) + 16*(rg & 1) + 4*he
+                const int pos = (wn >> 1) * 64 + 32 * (rg >> 1) + 8 * (wn & 1) + 16 * (rg & 1) + 4 * he;
+                const int chunk = (pos >> 4) ^ (r & 7);
+                *reinterpret_cast<int*>(rowp + chunk * 16 + (pos & 15)) = d;
+            }
+        }
+        SGLK_STAMP(26);
+        __syncthreads();
+        SGLK_STAMP(27);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tidv;
+            const int r = idx >> 3, pc = idx & 7, lc = pc ^ (r & 7);
+            if (r < cur.rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + r * 128 + pc * 16);
+                *reinterpret_cast<uint4*>((unsigned char*)p.out + (int64_t)(cur.pos0 + r) * p.out_stride + cur.ntile * 128 + lc * 16) = val;
+            }
+        }
+    } else if (MODE == MODE_GATE_UP) {
         // ic1 = bf16(silu(gate) * up) -- rounded to bf16 ONCE, as the bf16 kernel does -- for this workgroup's 128 columns = one K
         // block of GEMM-2, then split exactly like `hidden`: per-token amax over the four waves, power-of-two scale, (hi, lo),
         // stored [hi 64 | lo 64] per 64 group in the packed-tile k order
@@ -511,7 +585,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 #undef SGLK_STAMP
 }
 
-template <int MODE, int NMOD, int ABL>
+template <int MODE, int NMOD, int ABL, int TERMS>
 __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
     // Workgroup -> tile without knowing the tile count first (the table entry and the count are fetched side by side: one memory
@@ -533,10 +607,10 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8Gemm
     t.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     t.rows = __builtin_amdgcn_readfirstlane(ti.z);
     const int nta = (t.rows + 31) >> 5;
-    if (nta >= 4) run_tile<MODE, NMOD, ABL, 4>(p, smem, t);
-    else if (nta == 3) run_tile<MODE, NMOD, ABL, 3>(p, smem, t);
-    else if (nta == 2) run_tile<MODE, NMOD, ABL, 2>(p, smem, t);
-    else run_tile<MODE, NMOD, ABL, 1>(p, smem, t);
+    if (nta >= 4) run_tile<MODE, NMOD, ABL, 4, TERMS>(p, smem, t);
+    else if (nta == 3) run_tile<MODE, NMOD, ABL, 3, TERMS>(p, smem, t);
+    else if (nta == 2) run_tile<MODE, NMOD, ABL, 2, TERMS>(p, smem, t);
+    else run_tile<MODE, NMOD, ABL, 1, TERMS>(p, smem, t);
 }
 
 }  // namespace gs128
@@ -548,7 +622,7 @@ bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n) {
            block_n % 32 == 0;
 }
 
-int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream) {
+int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream, int terms) {
     if ((int64_t)max_mtiles * p.n_tiles == 0) return SGLK_OK;
     // groups of 8 m-tiles dealt round-robin to the 8 XCDs (see the kernel): every XCD gets the same number of workgroups
     const int64_t groups = ceil_div(max_mtiles, 8), groups_per_xcd = ceil_div(groups, 8);
@@ -561,8 +635,14 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
     if (p.xs_stride % 4 != 0 || ((uintptr_t)p.xs % 4) != 0) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: scale rows must be 4-byte aligned");
     if (mode != MODE_GATE_UP && mode != MODE_DOWN) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: mode %d", mode);
     const int nmod = (kblocks - 2) % 3;
-#define SGLK_LAUNCH_S128(M_, N_, A_) \
-    hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, A_>), dim3((unsigned)blocks), dim3(256), 0, stream, p)
+    if (terms != 1 && terms != 2) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: terms %d", terms);
+#define SGLK_LAUNCH_S128(M_, N_, A_)                                                                                      \
+    do {                                                                                                                  \
+        if (terms == 2)                                                                                                   \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, A_, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, p); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, p);  \
+    } while (0)
 #ifdef SGLK_DEV_ABLATE   // developer-only timing ablations (wrong results by design)
     const int abl = knobs().rescale_ablate;
 #define SGLK_LAUNCH_S128_B(M_, N_)                                                                 \

@@ -89,7 +89,8 @@ int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStrea
 int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
 // the same contract on 128-token tiles, four waves, two workgroups per CU, weights streamed global -> VGPR
 // (moe_gemm_fp8w_s128.hip); tile table built with tile_m = 128; GATE_UP n_tiles = N / 128, DOWN n_tiles = K / 256
-int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
+// terms = 2: x / ic1 rows are the two-term split (above); terms = 1: the a8 mode's quantised rows (moe_gemm_a8.hip's formats)
+int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream, int terms = 2);
 bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n);
 int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,
                               int64_t rows, int cols, hipStream_t stream);

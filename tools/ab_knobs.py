@@ -43,7 +43,7 @@ def main():
     dev = torch.device("cuda", 0)
     timer = L.sglk_stage_timer_create(args.iters + 8)
     if args.fp8_act:
-        sgl_kernel.set_fp8_activations(True)
+        _ops.set_fp8_activations(True)
     for M in [int(x) for x in args.tokens.split(",")]:
         a, w1, w2, w1s, w2s, tw, ids = bench.make_inputs(M, bench.N_EXPERTS, dev, 1111)
         w1p = [ops.convert_weight_packed(w1)]
