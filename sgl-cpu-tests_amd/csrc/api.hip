@@ -61,6 +61,7 @@ void read_env() {
     k.split = env_int("SGLK_SPLIT", -1);
     k.s128 = env_int("SGLK_S128", -1);
     k.a8_s128 = env_int("SGLK_A8_S128", -1);
+    k.i8_s128 = env_int("SGLK_I8_S128", -1);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);
     k.rescale_ablate = env_int("SGLK_RESCALE", 0);
     if (const char* dp = getenv("SGLK_DBG_PTR")) k.dbg_ptr = strtoull(dp, nullptr, 16);

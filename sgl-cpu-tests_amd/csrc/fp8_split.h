@@ -147,7 +147,10 @@ struct SplitJob {
     int64_t s_stride;       // bytes
     int64_t rows;
     int cols;
-    int terms;              // 2: the two-term split (q rows of 2 * cols bytes); 1: the a8 mode's quantised rows (cols bytes)
+    int terms;              // 2: the two-term split (q rows of 2 * cols bytes); 1: the a8 mode's quantised rows (cols bytes);
+                            // 0: the W8A8 operator's per-token int8 rows (quant_rows.h), one f32 factor per row in sf
+    float* sf;
+    float floor_v;
 };
 
 }  // namespace sglk

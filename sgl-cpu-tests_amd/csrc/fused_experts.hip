@@ -16,6 +16,7 @@ namespace {
 constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
 constexpr bool kS128Default = true;
 constexpr bool kA8S128Default = true;   // the opt-in a8 mode on the 128-token kernel when SGLK_A8_S128 is unset
+constexpr bool kI8S128Default = true;   // large-M int8 W8A8 on the 128-token kernel (exact int32 sums, ic1 quantised in GEMM-1's epilogue) when SGLK_I8_S128 is unset
     // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
 
 struct StageTimer {
@@ -25,7 +26,7 @@ struct StageTimer {
 };
 
 struct Workspace {
-    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tile_info_b, num_tiles_b, tickets, ic1, ic2, xq, xs, ic1q, ic1s, wpack, total;
+    size_t align_ws, sorted_slot, expert_off, tile_info, num_tiles, tile_info_b, num_tiles_b, tickets, ic1, ic2, xq, xs, ic1q, ic1s, i8_sync, i8_sync_bytes, wpack, total;
 };
 
 // Tile height of the tuned grouped GEMMs, from the average rows an expert receives (S/E).  Measured crossovers at Qwen3
@@ -104,6 +105,9 @@ Workspace plan_workspace(int M, int N, int K, int E, int topk, int wtype, int fl
         w.xs = take((size_t)M * sizeof(float));
         w.ic1q = take((size_t)S * N);
         w.ic1s = take((size_t)S * sizeof(float));
+        // 128-token kernel: per-row maxima of silu(gate) * up + one arrival counter per m-tile (zeroed in front of GEMM-1)
+        w.i8_sync_bytes = (size_t)S * sizeof(unsigned) + (size_t)sglk_moe_max_tiles(M, E, topk, kTileM) * sizeof(int);
+        w.i8_sync = take(w.i8_sync_bytes);
     }
     if (flags & SGLK_MOE_PACK_WEIGHTS)   // re-tiled copies of row-major w1 and w2
         w.wpack = take((size_t)E * 3 * N * K * (wtype == SGLK_W_BF16 ? 2 : 1));
@@ -283,6 +287,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     if (s128) tile_m = 128;
     const bool a8s = a8 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (knobs().a8_s128 >= 0 ? knobs().a8_s128 == 1 : kA8S128Default);
     if (a8s) tile_m = 128;
+    const bool i8s = tuned_i8 && moe_gemm_fp8w_s128_ok(N, K, 32) && (knobs().i8_s128 >= 0 ? knobs().i8_s128 == 1 : kI8S128Default);
+    if (i8s) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
     // tiles).  SGLK_TAIL_SPLIT=0 switches it off.
@@ -347,10 +353,21 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         sjob.cols = K;
         sjob.terms = 1;
     }
+    if (i8s) {   // the per-token int8 rows of `hidden` ride the same way
+        sjob.x = (const uint16_t*)a->hidden;
+        sjob.x_stride = a->hidden_stride;
+        sjob.q = ws + w.xq;
+        sjob.q_stride = K;
+        sjob.sf = (float*)(ws + w.xs);
+        sjob.floor_v = 1e-7f;
+        sjob.rows = M;
+        sjob.cols = K;
+        sjob.terms = 0;
+    }
     if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,
-                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), (want_split || a8) ? &sjob : nullptr,
+                                    w.sorted_slot - w.align_ws, stream, (int32_t*)(ws + w.tickets), (want_split || a8 || i8s) ? &sjob : nullptr,
                                     &split_done);
     if (rc != SGLK_OK) return rc;
     mark(1);
@@ -730,6 +747,74 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q2.topk = topk;
         q2.topk_weights = a->topk_weights;
         rc = launch_gemm_i8_mid(MODE_DOWN, q2, max_tiles, s);
+        if (rc != SGLK_OK) return rc;
+        mark(3);
+    } else if (i8s) {
+        // W8A8 on the 128-token kernel (moe_gemm_fp8w_s128.hip, terms = 0): x per token -> int8 (inside the align stage), GEMM-1
+        // + SiLU*mul + the per-token quantisation of ic1 in ONE launch (row maxima exchanged between the m-tile's workgroups),
+        // GEMM-2 + routing weight; same arithmetic, bit for bit, as the 256-row path below (/root/reference/test_moe_int8.py:59-94)
+        int8_t* xq = (int8_t*)(ws + w.xq);
+        float* xs = (float*)(ws + w.xs);
+        if (!split_done) {
+            rc = launch_quant_int8_rows((const uint16_t*)a->hidden, a->hidden_stride, xq, K, xs, M, K, 1e-7f, s);
+            if (rc != SGLK_OK) return rc;
+        }
+        if (hipMemsetAsync(ws + w.i8_sync, 0, w.i8_sync_bytes, s) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: memset failed");
+        mark(1);   // both count towards the align stage
+        int8_t* hq = (int8_t*)(ws + w.ic1q);
+        float* hs = (float*)(ws + w.ic1s);
+        A8GemmParams q1{};
+        q1.x = (const uint8_t*)xq;
+        q1.x_stride = K;
+        q1.x_bytes = (int64_t)M * K;
+        q1.x_scale_f32 = xs;
+        q1.sorted_slot = sorted_slot;
+        q1.topk = topk;
+        q1.w = (const uint8_t*)a->w1;
+        q1.w_expert_stride = (int64_t)2 * N * K;
+        q1.w_scale = a->w1_scale;
+        q1.scale_rows = 2 * N;
+        q1.C = K;
+        q1.n_half = N;
+        q1.tile_info = (const int4*)tile_info;
+        q1.num_tiles = num_tiles;
+        q1.n_tiles = N / 128;
+        q1.out = hq;
+        q1.out_stride = N;
+        q1.out_scale_f32 = hs;
+        q1.row_amax = (unsigned*)(ws + w.i8_sync);
+        q1.arrivals = (int*)(ws + w.i8_sync + (size_t)M * topk * sizeof(unsigned));
+        q1.quant_floor = 1e-7f;
+        q1.max_mtiles = max_tiles;
+#ifdef SGLK_DEV_ABLATE
+        if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
+#endif
+        rc = launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s, 0);
+        if (rc != SGLK_OK) return rc;
+        mark(2);
+        A8GemmParams q2{};
+        q2.x = (const uint8_t*)hq;
+        q2.x_stride = N;
+        q2.x_bytes = (int64_t)M * topk * N;
+        q2.x_scale_f32 = hs;
+        q2.sorted_slot = sorted_slot;
+        q2.topk = topk;
+        q2.w = (const uint8_t*)a->w2;
+        q2.w_expert_stride = (int64_t)K * N;
+        q2.w_scale = a->w2_scale;
+        q2.scale_rows = K;
+        q2.C = N;
+        q2.tile_info = (const int4*)tile_info;
+        q2.num_tiles = num_tiles;
+        q2.n_tiles = K / 256;
+        q2.out = ic2;
+        q2.out_stride = K;
+        q2.topk_weights = a->topk_weights;
+        q2.max_mtiles = max_tiles;
+#ifdef SGLK_DEV_ABLATE
+        if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
+#endif
+        rc = launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s, 0);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else if (tuned_i8) {

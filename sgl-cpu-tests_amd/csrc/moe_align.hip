@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "fp8_split.h"
+#include "quant_rows.h"
 #include "knobs.h"
 #include "moe_align_small.h"
 
@@ -57,7 +58,9 @@ __global__ __launch_bounds__(256) void moe_place_kernel(const int* __restrict__ 
     if ((int)blockIdx.x >= place_blocks) {
         const int64_t row = (int64_t)((int)blockIdx.x - place_blocks) * 4 + (threadIdx.x >> 6);
         if (row < job.rows) {
-            if (job.terms == 2)
+            if (job.terms == 0)
+                quant_row_int8(job.x + row * job.x_stride, (int8_t*)(job.q + row * job.q_stride), job.sf + row, job.cols, job.floor_v, threadIdx.x & 63);
+            else if (job.terms == 2)
                 split_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);
             else
                 quant_row_block128(job.x + row * job.x_stride, job.q + row * job.q_stride, job.s + row * job.s_stride, job.cols, threadIdx.x & 63);

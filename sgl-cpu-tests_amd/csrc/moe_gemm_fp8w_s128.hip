@@ -34,6 +34,7 @@ namespace sglk {
 
 typedef __attribute__((address_space(3))) void* lptr_s1_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 namespace gs128 {
 
@@ -67,7 +68,7 @@ SGLK_DEV void split_scale(float s_in, int& eb, float& mant) {
 enum { KB_STEADY = 0, KB_PENULT = 1, KB_LAST = 2 };
 
 struct TileId {
-    int L, ntile, e, pos0, rows;   // L = linear tile id (time stamps of developer builds only)
+    int L, mt, ntile, e, pos0, rows;   // L = linear tile id (time stamps of developer builds only), mt = m-tile
 };
 
 // One tile.
@@ -82,8 +83,15 @@ struct TileId {
 // TERMS = e4m3 terms per activation: 2 = the exact two-term split of the bf16 value (W8A16, the reference's numerics); 1 = the
 // opt-in a8 mode (activations QUANTISED to e4m3 per token x 128 block: moe_gemm_a8.hip's formats and oracle, half the MFMAs,
 // X bytes and LDS reads per stage).
-template <int MODE, int NMOD, int ABL, int NTA, int TERMS>
+// I8 = the int8 W8A8 operator (/root/reference/test_moe_int8.py:59-94, bench_moe.py:89-106) on the same pipeline: one int8 term
+// per activation (TERMS = 1 data movement), weights in pack.hip's int8 tiles (natural k order), two mfma_i32_32x32x32_i8 per
+// 64-deep slot (the lane's two 16-byte halves; exact int32 sums), NO scales inside the loop: the per-token and per-weight-row
+// factors are applied in the epilogue in the oracle's order.  GATE_UP quantises silu(gate) * up per token over the WHOLE row
+// (the oracle's per_token_quant_int8), which spans the m-tile's n_tiles workgroups: they exchange the row maxima through
+// global atomics and a per-m-tile arrival counter (see the epilogue).
+template <int MODE, int NMOD, int ABL, int NTA, int TERMS, bool I8>
 SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId cur) {
+    static_assert(!I8 || TERMS == 1, "int8 moves one byte per activation");
     constexpr int kXB = 64 * TERMS;             // activation bytes per token and stage
     constexpr int kStageXT = kBM * kXB;         // ring slot: 16 KiB (two terms) / 8 KiB
     constexpr int kXP = 2 * TERMS;              // 1-KiB LDS-DMA pieces of a stage per wave
@@ -129,8 +137,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     const int xo_l0 = r32 * kXB + (((4 + 2 * h) ^ sw) << 4), xo_l1 = r32 * kXB + (((5 + 2 * h) ^ sw) << 4);   // two terms only
 
     // ---- prologue loads (parked in registers; written to the LDS tables after the first operand loads have been issued) ----
-    float sc_reg[2];
-    {
+    float sc_reg[2] = {0.f, 0.f};
+    if (I8) {   // per-weight-row factors of the workgroup's 256 rows: sc[piece * 16 + row of the piece]
+        sc_reg[0] = p.w_scale[(int64_t)cur.e * p.scale_rows + piece_row16(tid >> 4) * 16 + (tid & 15)];
+    } else {
         const float* scale_e = p.w_scale + (int64_t)cur.e * p.scale_rows * p.scale_cols;
         const float inv_bn = 1.0f / (float)p.block_n;
 #pragma unroll
@@ -146,15 +156,20 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     }
     int my_slot = -1;
     unsigned xs_reg[kMaxKB / 4];
+    float xs_f32 = 0.f;   // int8: the token's dequantisation factor
 #pragma unroll
     for (int i = 0; i < kMaxKB / 4; ++i) xs_reg[i] = 0x7f7f7f7fu;
     if (tid < kBM && tid < cur.rows) {
         const int slot = p.sorted_slot[cur.pos0 + tid];
         const int64_t xrow = (MODE == MODE_GATE_UP) ? (int64_t)(slot / p.topk) : (int64_t)(cur.pos0 + tid);
-        const unsigned* sp = reinterpret_cast<const unsigned*>(p.xs + xrow * p.xs_stride);
+        if (I8) {
+            xs_f32 = p.x_scale_f32[xrow];
+        } else {
+            const unsigned* sp = reinterpret_cast<const unsigned*>(p.xs + xrow * p.xs_stride);
 #pragma unroll
-        for (int i = 0; i < kMaxKB / 4; ++i)
-            if (i * 4 < kblocks) xs_reg[i] = sp[i];
+            for (int i = 0; i < kMaxKB / 4; ++i)
+                if (i * 4 < kblocks) xs_reg[i] = sp[i];
+        }
         if (MODE == MODE_DOWN) my_slot = slot;   // its routing weight (a dependent load) is fetched near the end of the main loop
     }
 
@@ -187,64 +202,98 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     auto issue_x = [&](int kt, int buf, int i) __attribute__((always_inline)) {   // piece i (0..3) of this wave, stage kt
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_s1_t)(smem + buf * kStageXT + (wn * kXP + i) * 1024), 16, xsrc[i], kt * kXB, 0, 0);
     };
-    i32x8 fa[3][2] = {};                   // [(stage + const) % 3][row tile]
+    i32x8 fa[TERMS == 1 ? 4 : 3][2] = {};   // [(stage + const) % 3][row tile]; one term: [stage % 4][row tile], weights three stages ahead
     auto ld_a = [&](int as, int rt, int kt) __attribute__((always_inline)) {
         const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[rt], kt * 1024, 0);
         const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[rt], kt * 1024 + 256, 0);   // + 16 slots: in the scalar offset
         fa[as][rt] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
 
+    auto ld_a_half = [&](int as, int rt, int kt, int half) __attribute__((always_inline)) {   // one of the two loads of ld_a
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc[rt], kt * 1024 + half * 256, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[as][rt][half * 4 + i] = (int)v[i];
+    };
+
     // ---- prologue: X(0) A(0) X(1) A(1) X(2) and half of X(3) in flight (in this order: the counted waits rely on it) ----
-    constexpr int kSet0 = NMOD == 0 ? 2 : (NMOD == 1 ? 0 : 1);   // fragment set of stage 0 = first set of K block 0's phase
+    // One term (a stage is half as long in time, so everything is requested further ahead: the ring holds EIGHT 8-KiB stages,
+    // the weights come three stages ahead into four register sets): X(0..4) A(0) X(5) A(1) X(6) A(2) X(7) -- the order the steady
+    // state would have issued them in.  Stages past the end of a short reduction are requested all the same (they land in ring
+    // slots nobody reads; the counted waits stay the same for every length).
+    constexpr int kSet0 = TERMS == 1 ? 2 * NMOD : (NMOD == 0 ? 2 : (NMOD == 1 ? 0 : 1));   // fragment set of stage 0 = first set of K block 0's phase
+    if constexpr (TERMS == 1) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < 5; ++st) {
+            issue_x(st, st, 0);
+            issue_x(st, st, 1);
+        }
 #pragma unroll
-        for (int i = 0; i < kXP; ++i) issue_x(st, st, i);
-        ld_a((kSet0 + st) % 3, 0, st);
-        ld_a((kSet0 + st) % 3, 1, st);
+        for (int st = 0; st < 3; ++st) {
+            ld_a((kSet0 + st) % 4, 0, st);
+            ld_a((kSet0 + st) % 4, 1, st);
+            issue_x(5 + st, 5 + st, 0);
+            issue_x(5 + st, 5 + st, 1);
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+#pragma unroll
+            for (int i = 0; i < kXP; ++i) issue_x(st, st, i);
+            ld_a((kSet0 + st) % 3, 0, st);
+            ld_a((kSet0 + st) % 3, 1, st);
+        }
+#pragma unroll
+        for (int i = 0; i < kXP; ++i) issue_x(2, 2, i);
+        issue_x(3, 3, 0);   // two terms: pieces 2, 3 of X(3) are carried into stage 0 like every later stage's
+        issue_x(3, 3, 1);
     }
-#pragma unroll
-    for (int i = 0; i < kXP; ++i) issue_x(2, 2, i);
-    issue_x(3, 3, 0);   // two terms: pieces 2, 3 of X(3) are carried into stage 0 like every later stage's
-    issue_x(3, 3, 1);
     sc[tid] = sc_reg[0];
-    sc[tid + 256] = sc_reg[1];
+    if (!I8) sc[tid + 256] = sc_reg[1];
     if (tid < kBM) {
+        if (I8) {
+            reinterpret_cast<float*>(xs_tab)[tid] = xs_f32;
+        } else {
 #pragma unroll
-        for (int i = 0; i < kMaxKB / 4; ++i)
-            if (i * 4 < kblocks) {
+            for (int i = 0; i < kMaxKB / 4; ++i)
+                if (i * 4 < kblocks) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) xs_tab[(i * 4 + b) * kBM + tid] = (unsigned char)(xs_reg[i] >> (8 * b));
-            }
+                    for (int b = 0; b < 4; ++b) xs_tab[(i * 4 + b) * kBM + tid] = (unsigned char)(xs_reg[i] >> (8 * b));
+                }
+        }
         if (MODE == MODE_DOWN) slot_tab[tid] = my_slot;
     }
-    // X(0) and A(0) have landed; X(1) A(1) X(2) + two pieces of X(3) = 14 (two terms) / 10 operations stay in flight
-    if (TERMS == 2) __builtin_amdgcn_s_waitcnt(wc(14, 0));
-    else __builtin_amdgcn_s_waitcnt(wc(10, 0));
+    // X(0) and A(0) have landed; X(1) A(1) X(2) + two pieces of X(3) = 14 operations stay in flight
+    // (one term: X(5) A(1) X(6) A(2) X(7) = 14 as well)
+    __builtin_amdgcn_s_waitcnt(wc(14, 0));
     __builtin_amdgcn_s_barrier();
 
-    f32x16 acc[2][4];
+    typedef typename std::conditional<I8, i32x16, f32x16>::type acc_t;   // int8: exact int32 sums
+    acc_t acc[2][4];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0.f;
+            for (int i = 0; i < 16; ++i) acc[rt][tt][i] = 0;
     float my_tw = 0.f;
 
-    int ea[2], ea_next[2];
-    float mant[2], ratio[2];
+    int ea[2] = {0, 0}, ea_next[2] = {0, 0};
+    float mant[2] = {1.f, 1.f}, ratio[2] = {1.f, 1.f};
+    if (!I8) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        split_scale(sc[wpiece0[rt] * kMaxKB], ea[rt], mant[rt]);
-        ea_next[rt] = ea[rt];
-        ratio[rt] = 1.f;
+        for (int rt = 0; rt < 2; ++rt) {
+            split_scale(sc[wpiece0[rt] * kMaxKB], ea[rt], mant[rt]);
+            ea_next[rt] = ea[rt];
+            ratio[rt] = 1.f;
+        }
     }
     // B scale bytes of the lane's four tokens for the current K block (the lo term's scale is this - 4); token tile tt's byte
     // of the NEXT block is read into the same register right behind the tile's last MFMA of the block
-    int xsv[4];
+    int xsv[4] = {0, 0, 0, 0};
+    if (!I8) {
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) xsv[tt] = xs_tab[tt * 32 + r32];
+        for (int tt = 0; tt < 4; ++tt) xsv[tt] = xs_tab[tt * 32 + r32];
+    }
 
 #define SGLK_FENCE() __builtin_amdgcn_sched_barrier(0)
     // ONE window of token fragments (hi / lo of a 32-token tile): the next tile's fragment is requested right behind the last
@@ -271,12 +320,17 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     // MFMA slot s of a stage.  Two terms (16 per wave): token tile s >> 2, then hi x rt0, hi x rt1, lo x rt0, lo x rt1; one term
     // (8): token tile s >> 1, then rt0, rt1
     auto mma = [&](int as, int s2) __attribute__((always_inline)) {
-        if (TERMS == 2) {
+        if constexpr (TERMS == 2) {
             const int tt = s2 >> 2, lo = (s2 >> 1) & 1, rt = s2 & 1;
             if (lo)
                 acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bl, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt] - 4);
             else
                 acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], bh, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
+        } else if constexpr (I8) {
+            const int tt = s2 >> 1, rt = s2 & 1;
+            const i32x8 a = fa[as][rt], b = (tt & 1) ? bl : bh;   // the same k runs in both halves of A and B
+            acc[rt][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{a[0], a[1], a[2], a[3]}, i32x4{b[0], b[1], b[2], b[3]}, acc[rt][tt], 0, 0, 0);
+            acc[rt][tt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(i32x4{a[4], a[5], a[6], a[7]}, i32x4{b[4], b[5], b[6], b[7]}, acc[rt][tt], 0, 0, 0);
         } else {
             const int tt = s2 >> 1, rt = s2 & 1;
             acc[rt][tt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[as][rt], (tt & 1) ? bl : bh, acc[rt][tt], 0, 0, 0, ea[rt], 0, xsv[tt]);
@@ -285,7 +339,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     // accumulator tile (rt, tt) into units of the next K block's mantissa, four registers (chunk c) at a time: a wave that has
     // its SIMD to itself is issue-bound, so the 128 multiplies of a K-block boundary are spread four per tile and MFMA slot
     auto rescale4 = [&](int rt, int tt, int c) __attribute__((always_inline)) {
-        if (ABL & 1) return;
+        if ((ABL & 1) || I8) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][c * 4 + i]) : "s"(ratio[rt]));
     };
@@ -325,16 +379,16 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         int nbuf = buf + 1;
         if (nbuf == kRing) nbuf = 0;
         const int as2 = (as + 2) % 3;
-        if (first) {   // this block's weight scale (computed one stage ago) becomes current
+        if (first && !I8) {   // this block's weight scale (computed one stage ago) becomes current
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) ea[rt] = ea_next[rt];
         }
-        if (pre) {
+        if (pre && !I8) {
             const int kb = (t >> 1) + 1;
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) nsc[rt] = sc[wpiece0[rt] * kMaxKB + kb];
         }
-        if (bound) {
+        if (bound && !I8) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 float nm;
@@ -354,13 +408,13 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             } else {            // the other window has been free since the previous tile's second MFMA
                 if (q == 0 && tt + 1 < NTA) ld_bh(tt + 1, buf);
             }
-            if (q == kSP / 4 - 1 && bound && tt < NTA) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
+            if (q == kSP / 4 - 1 && bound && tt < NTA && !I8) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
             if (s2 == 0 && lda && !(ABL & 4)) ld_a(as2, 0, t + 2);
             if (s2 == kSP / 4 && lda && !(ABL & 4)) ld_a(as2, 1, t + 2);
             if (TERMS == 2 && s2 == 2 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 2);
             if (TERMS == 2 && s2 == 6 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 3);
-            if (bound) rescale_slot(s2);
-            if (first) rescale_slot(kSP + s2);
+            if (bound && !I8) rescale_slot(s2);
+            if (first && !I8) rescale_slot(kSP + s2);
             if (s2 == kSP - 3 + (TERMS == 1) && wait >= 0) {   // behind slot 13 (two terms) / 6: every fragment of this stage has been read
                 if (wait == 2) __builtin_amdgcn_s_waitcnt(wc(TERMS == 2 ? 9 : 6, 0));
                 else if (wait == 1) __builtin_amdgcn_s_waitcnt(wc(TERMS == 2 ? 5 : 4, 0));
@@ -393,9 +447,89 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             stage(a1, t + 1, false, false, -1, false, false, false, false);
         }
     };
-    {
+    // ---- one term: the deep form.  Stage t (ring slot t % 8, fragment set t % 4) requests A(t+3) (slots 0, 2) and, behind its
+    // sync point, X(t+8) into its own ring slot.  d = stages left after this one (a literal; kFar in the steady state): what
+    // still exists to be requested, and how many of the wave's youngest operations may stay in flight at the sync point
+    // (X(t+1) and A(t+1) have landed): the operations issued behind A(t+1) --
+    //   stage t-2: X(t+6) [d+2 >= 8]; stage t-1: A(t+2) [d+1 >= 3], X(t+7) [d+1 >= 8]; stage t: A(t+3) [d >= 3]
+    constexpr int kFar = 64;
+    auto stage1 = [&](int as, int t, bool first, bool bound, bool pre, int d) __attribute__((always_inline)) {
+        int nbuf = buf + 1;
+        if (nbuf == 8) nbuf = 0;
+        const int as3 = (as + 3) & 3;
+        const bool lda = d >= 3, dmax = d >= 8;
+        const int n_wait = (d + 2 >= 8 ? 2 : 0) + (d + 1 >= 3 ? 4 : 0) + (d + 1 >= 8 ? 2 : 0) + (d >= 3 ? 4 : 0);
+        if (first && !I8) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) ea[rt] = ea_next[rt];
+        }
+        if (pre && !I8) {
+            const int kb = (t >> 1) + 1;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) nsc[rt] = sc[wpiece0[rt] * kMaxKB + kb];
+        }
+        if (bound && !I8) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float nm;
+                split_scale(nsc[rt], ea_next[rt], nm);
+                ratio[rt] = uniform_f32(mant[rt] * __builtin_amdgcn_rcpf(nm));
+                mant[rt] = nm;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int tt = s2 >> 1, q = s2 & 1;
+            if (tt < NTA) mma(as, s2);
+            SGLK_FENCE();
+            if (q == 0 && tt + 1 < NTA && !((ABL & 32) && d >= kFar)) ld_bh(tt + 1, buf);   // the other window has been free since the previous tile's second MFMA
+            if (q == 1 && bound && tt < NTA && !I8) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
+            // one vector-memory instruction per MFMA slot (the four waves run in step, so a burst of one wave is a burst of four
+            // in front of the CU's one 64-byte-per-clock address path)
+            if (s2 < 4 && lda && !((ABL & 4) && d >= kFar)) ld_a_half(as3, s2 >> 1, t + 3, s2 & 1);
+            if (bound && !I8) rescale_slot(s2);
+            if (first && !I8) rescale_slot(8 + s2);
+            if (s2 == 6 && d >= 1) {   // every fragment of this stage has been read
+                if ((ABL & 16) && d >= kFar) __builtin_amdgcn_s_waitcnt(wc(63, 0));   // developer builds: ABL = timing ablations, wrong results
+                else if (n_wait == 12) __builtin_amdgcn_s_waitcnt(wc(12, 0));        // (the builtin wants a literal)
+                else if (n_wait == 10) __builtin_amdgcn_s_waitcnt(wc(10, 0));
+                else if (n_wait == 8) __builtin_amdgcn_s_waitcnt(wc(8, 0));
+                else if (n_wait == 4) __builtin_amdgcn_s_waitcnt(wc(4, 0));
+                else __builtin_amdgcn_s_waitcnt(wc(0, 0));
+                if (!((ABL & 8) && d >= kFar)) __builtin_amdgcn_s_barrier();
+                if (!((ABL & 32) && d >= kFar)) ld_bh(0, nbuf);
+            }
+            if (s2 == 6 && dmax && !((ABL & 2) && d >= kFar)) issue_x(t + 8, buf, 0);
+            if (s2 == 7 && dmax && !((ABL & 2) && d >= kFar)) issue_x(t + 8, buf, 1);
+            SGLK_FENCE();
+        }
+        buf = nbuf;
+    };
+    // K block kb in phase ph (sets 2 ph, 2 ph + 1), e = K blocks behind it (a literal; kFar: at least four)
+    auto kblock1 = [&](int ph, int e, int kb) __attribute__((always_inline)) {
+        const int t = 2 * kb;
+        if (MODE == MODE_DOWN && e == 0 && my_slot >= 0) my_tw = p.topk_weights[my_slot];   // covered by stage T-2's vmcnt(0)
+        stage1(2 * ph, t, true, false, e >= 1, e >= kFar ? kFar : 2 * e + 1);
+        stage1(2 * ph + 1, t + 1, false, e >= 1, false, e >= kFar ? kFar : 2 * e);
+    };
+    if constexpr (TERMS == 1) {
+        // phases from the END of the reduction (literal set indices): the last four blocks run in phases 0 1 0 1; NMOD = kblocks % 2
+        // = the phase of block 0
         ld_bh(0, 0);
-        if (TERMS == 2) ld_bl(0, 0);
+        SGLK_FENCE();
+        int kb = 0;
+        if (NMOD == 1 && kblocks >= 5) kblock1(1, kFar, kb++);
+        for (; kb + 2 <= kblocks - 4; kb += 2) {
+            kblock1(0, kFar, kb);
+            kblock1(1, kFar, kb + 1);
+        }
+        if (kblocks >= 4) kblock1(0, 3, kb++);
+        if (kblocks >= 3) kblock1(1, 2, kb++);
+        kblock1(0, 1, kb++);
+        kblock1(1, 0, kb);
+    } else {
+        ld_bh(0, 0);
+        ld_bl(0, 0);
         SGLK_FENCE();
         int kb = 0;
         if (NMOD == 2) kblock(2, KB_STEADY, kb++);
@@ -425,7 +559,140 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     int tidv = tid;
     asm volatile("" : "+v"(tidv));
     const int r32e = tidv & 31, he = (tidv >> 5) & 1;
-    if (MODE == MODE_GATE_UP && TERMS == 1) {
+    if constexpr (I8 && MODE == MODE_GATE_UP) {
+        // int8: h = silu(gate) * up in fp32 exactly as gemm_i8_256.hip forms it ((xs * acc) * ws, separately rounded), then the
+        // oracle's per-token quantisation over the WHOLE row of N columns (test_moe_int8.py:23-31,83-86): this workgroup holds
+        // 128 of them, the m-tile's other n_tiles - 1 workgroups the rest.  Every workgroup adds its rows' maxima to
+        // row_amax[position] (atomic max on the bit pattern of a non-negative float), then announces itself on the m-tile's
+        // arrival counter and waits until all n_tiles have: the n_tiles workgroups of an m-tile are consecutive workgroups of
+        // one XCD (see the kernel), dispatched in order, so whoever waits waits for workgroups that are already running or next
+        // in line -- at most one m-tile per XCD is ever partly dispatched, and its waiters hold at most n_tiles - 1 slots.
+        // (The wait is bounded all the same: on expiry the rows' scale becomes NaN instead of the launch hanging.)
+        const float* ws_tab = sc;
+        const float* xs_f = reinterpret_cast<const float*>(xs_tab);
+        float v[4][16];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const float xs = xs_f[tt * 32 + r32e];
+            float am = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * he;
+                const float g = xs * (float)acc[0][tt][i] * ws_tab[wpiece0[0] * 16 + row];
+                const float u = xs * (float)acc[1][tt][i] * ws_tab[wpiece0[1] * 16 + row];
+                v[tt][i] = silu_f32(g) * u;
+                am = fmaxf(am, fabsf(v[tt][i]));
+            }
+            am = fmaxf(am, __shfl_xor(am, 32));
+            if (he == 0) amax_tab[wn * kBM + tt * 32 + r32e] = am;
+        }
+        __syncthreads();
+        // Everything the workgroups tell each other travels in device-scope atomics (performed at the memory side, relaxed):
+        // no release / acquire at agent scope, which on this chip means writing back / invalidating the XCD's whole L2 under
+        // the neighbours' operand streams (measured: GEMM-1 3x slower).  The maxima are RETURNING atomics, so the counted wait
+        // in front of the barrier sees them performed before thread 0 announces the workgroup.
+        if (tidv < kBM && tidv < cur.rows) {
+            const float am = fmaxf(fmaxf(amax_tab[tidv], amax_tab[kBM + tidv]), fmaxf(amax_tab[2 * kBM + tidv], amax_tab[3 * kBM + tidv]));
+            const unsigned old = __hip_atomic_fetch_max(p.row_amax + cur.pos0 + tidv, __float_as_uint(am), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        SGLK_STAMP(28);
+        int* flag = reinterpret_cast<int*>(smem + kRowTabOff);   // GATE_UP has no row table
+        if (tidv == 0) {
+            const int before = __hip_atomic_fetch_add(p.arrivals + cur.mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int it = 0;
+            if (before + 1 < p.n_tiles) {
+                while (__hip_atomic_load(p.arrivals + cur.mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.n_tiles && it < (1 << 22)) {
+                    __builtin_amdgcn_s_sleep(4);
+                    ++it;
+                }
+            }
+            flag[0] = it >= (1 << 22);
+        }
+        __syncthreads();
+        SGLK_STAMP(29);
+        if (tidv < kBM) {
+            unsigned u = 0u;
+            if (tidv < cur.rows) u = __hip_atomic_load(p.row_amax + cur.pos0 + tidv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            amax_tab[tidv] = flag[0] ? __uint_as_float(0x7fc00000u) : __uint_as_float(u);
+        }
+        __syncthreads();
+        SGLK_STAMP(30);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int r = tt * 32 + r32e;
+            // as quant_int8_rows_f32_kernel (quant.hip): torch evaluates 127 / absmax as reciprocal(absmax) * 127
+            const float am = fmaxf(amax_tab[r], p.quant_floor);
+            const float inv = (1.0f / am) * 127.0f;
+            if (cur.ntile == 0 && wn == 0 && he == 0 && r < cur.rows) p.out_scale_f32[cur.pos0 + r] = am / 127.0f;
+            unsigned char* rowp = smem + r * 128;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                unsigned d = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d |= ((unsigned)((int)rintf(v[tt][rg * 4 + j] * inv) & 0xff)) << (8 * j);
+                const int pos = wn * 32 + rg * 8 + he * 4;   // natural column order (pack.hip's int8 tiles keep k in order)
+                const int chunk = (pos >> 4) ^ (r & 7);
+                *reinterpret_cast<unsigned*>(rowp + chunk * 16 + (pos & 15)) = d;
+            }
+        }
+        SGLK_STAMP(26);
+        __syncthreads();
+        SGLK_STAMP(27);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = it * 256 + tidv;
+            const int r = idx >> 3, pc = idx & 7, lc = pc ^ (r & 7);
+            if (r < cur.rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + r * 128 + pc * 16);
+                *reinterpret_cast<uint4*>((unsigned char*)p.out + (int64_t)(cur.pos0 + r) * p.out_stride + cur.ntile * 128 + lc * 16) = val;
+            }
+        }
+    } else if constexpr (I8) {
+        // int8 DOWN: ic2[slot] = ((xs * acc) * ws) * topk_w in bf16, the fp8 form's image and stores
+        constexpr int kRowB = 512;
+        const float* ws_tab = sc;
+        const float* xs_f = reinterpret_cast<const float*>(xs_tab);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int r = tt * 32 + r32e;
+            unsigned char* rowp = smem + r * kRowB;
+            const float tw = tw_tab[r], xs = xs_f[r];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = xs * (float)acc[rt][tt][rg * 4 + j] * ws_tab[wpiece0[rt] * 16 + rg * 8 + he * 4 + j];
+                        o[j] *= tw;
+                    }
+                    uint2 val;
+                    val.x = pack_bf16x2(o[0], o[1]);
+                    val.y = pack_bf16x2(o[2], o[3]);
+                    const int col = wn * 64 + rt * 32 + rg * 8 + he * 4;
+                    const int chunk = (col >> 3) ^ (r & 15);
+                    *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = val;
+                }
+            }
+        }
+        SGLK_STAMP(26);
+        __syncthreads();
+        SGLK_STAMP(27);
+        uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = it * 256 + tidv;
+            const int r = idx >> 5, pc = idx & 31, lc = pc ^ (r & 15);
+            if (r < cur.rows) {
+                const uint4 val = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
+                *reinterpret_cast<uint4*>(outp + (int64_t)slot_tab[r] * p.out_stride + cur.ntile * 256 + lc * 8) = val;
+            }
+        }
+    } else if constexpr (MODE == MODE_GATE_UP && TERMS == 1) {
         // a8: ic1 = silu(gate) * up for this workgroup's 128 columns = ONE K block of GEMM-2, quantised like `hidden`: per-token
         // amax over the four waves, power-of-two scale, e4m3, stored in the packed-tile k order (moe_gemm_a8.hip's formats)
         float v[4][16];
@@ -474,7 +741,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
                 *reinterpret_cast<uint4*>((unsigned char*)p.out + (int64_t)(cur.pos0 + r) * p.out_stride + cur.ntile * 128 + lc * 16) = val;
             }
         }
-    } else if (MODE == MODE_GATE_UP) {
+    } else if constexpr (MODE == MODE_GATE_UP) {
         // ic1 = bf16(silu(gate) * up) -- rounded to bf16 ONCE, as the bf16 kernel does -- for this workgroup's 128 columns = one K
         // block of GEMM-2, then split exactly like `hidden`: per-token amax over the four waves, power-of-two scale, (hi, lo),
         // stored [hi 64 | lo 64] per 64 group in the packed-tile k order
@@ -585,7 +852,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 #undef SGLK_STAMP
 }
 
-template <int MODE, int NMOD, int ABL, int TERMS>
+template <int MODE, int NMOD, int ABL, int TERMS, bool I8>
 __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8GemmParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLds];
     // Workgroup -> tile without knowing the tile count first (the table entry and the count are fetched side by side: one memory
@@ -600,6 +867,7 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8Gemm
     const int mt = (gi * 8 + x) * kGroup + mi;
     TileId t;
     t.ntile = rem - mi * p.n_tiles;
+    t.mt = mt;
     t.L = mt * p.n_tiles + t.ntile;
     const int4 ti = p.tile_info[mt < p.max_mtiles ? mt : 0];
     if (mt >= p.num_tiles[0]) return;
@@ -607,10 +875,10 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8Gemm
     t.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     t.rows = __builtin_amdgcn_readfirstlane(ti.z);
     const int nta = (t.rows + 31) >> 5;
-    if (nta >= 4) run_tile<MODE, NMOD, ABL, 4, TERMS>(p, smem, t);
-    else if (nta == 3) run_tile<MODE, NMOD, ABL, 3, TERMS>(p, smem, t);
-    else if (nta == 2) run_tile<MODE, NMOD, ABL, 2, TERMS>(p, smem, t);
-    else run_tile<MODE, NMOD, ABL, 1, TERMS>(p, smem, t);
+    if (nta >= 4) run_tile<MODE, NMOD, ABL, 4, TERMS, I8>(p, smem, t);
+    else if (nta == 3) run_tile<MODE, NMOD, ABL, 3, TERMS, I8>(p, smem, t);
+    else if (nta == 2) run_tile<MODE, NMOD, ABL, 2, TERMS, I8>(p, smem, t);
+    else run_tile<MODE, NMOD, ABL, 1, TERMS, I8>(p, smem, t);
 }
 
 }  // namespace gs128
@@ -631,17 +899,21 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
     const int kblocks = p.C >> 7;
     if (p.C % 128 != 0 || kblocks < 2 || kblocks > gs128::kMaxKB)
         SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: reduction length %d (needs 2..%d whole 128-wide K blocks)", p.C, gs128::kMaxKB);
-    if (p.block_n % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: block_n %d is not a multiple of 32", p.block_n);
-    if (p.xs_stride % 4 != 0 || ((uintptr_t)p.xs % 4) != 0) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: scale rows must be 4-byte aligned");
+    if (terms != 0 && p.block_n % 32 != 0) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_s128: block_n %d is not a multiple of 32", p.block_n);
+    if (terms != 0 && (p.xs_stride % 4 != 0 || ((uintptr_t)p.xs % 4) != 0)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: scale rows must be 4-byte aligned");
+    if (terms == 0 && (!p.x_scale_f32 || (mode == MODE_GATE_UP && (!p.out_scale_f32 || !p.row_amax || !p.arrivals))))
+        SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: int8 needs the per-row scale tables and the row-maximum exchange buffers");
     if (mode != MODE_GATE_UP && mode != MODE_DOWN) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: mode %d", mode);
-    const int nmod = (kblocks - 2) % 3;
-    if (terms != 1 && terms != 2) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: terms %d", terms);
+    const int nmod = terms == 2 ? (kblocks - 2) % 3 : kblocks % 2;   // see run_tile: the rotation of the fragment sets
+    if (terms < 0 || terms > 2) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: terms %d", terms);
 #define SGLK_LAUNCH_S128(M_, N_, A_)                                                                                      \
     do {                                                                                                                  \
         if (terms == 2)                                                                                                   \
-            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, A_, 2>), dim3((unsigned)blocks), dim3(256), 0, stream, p); \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, A_, 2, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p); \
+        else if (terms == 1)                                                                                              \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, (N_) & 1, 0, 1, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);  \
         else                                                                                                              \
-            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, N_, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, p);  \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<M_, (N_) & 1, 0, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);   \
     } while (0)
 #ifdef SGLK_DEV_ABLATE   // developer-only timing ablations (wrong results by design)
     const int abl = knobs().rescale_ablate;
@@ -655,6 +927,26 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
             default: SGLK_LAUNCH_S128(M_, N_, 0); break;                                           \
         }                                                                                          \
     } while (0)
+    // one-term int8 GEMM-1: 2 no X DMA, 4 no weight loads, 8 no barrier, 16 no counted wait, 32 no fragment reads (steady state)
+#define SGLK_LAUNCH_S128_I8ABL(N_, A_) \
+    hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<MODE_GATE_UP, N_, A_, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p)
+    if (terms == 0 && mode == MODE_GATE_UP && abl >= 100) {
+        const int a2 = abl - 100;
+        if (nmod == 0) {
+            switch (a2) {
+                case 2: SGLK_LAUNCH_S128_I8ABL(0, 2); break;
+                case 4: SGLK_LAUNCH_S128_I8ABL(0, 4); break;
+                case 8: SGLK_LAUNCH_S128_I8ABL(0, 8); break;
+                case 24: SGLK_LAUNCH_S128_I8ABL(0, 24); break;
+                case 32: SGLK_LAUNCH_S128_I8ABL(0, 32); break;
+                case 62: SGLK_LAUNCH_S128_I8ABL(0, 62); break;
+                default: SGLK_LAUNCH_S128_I8ABL(0, 0); break;
+            }
+            SGLK_CHECK_LAUNCH("moe_gemm_fp8w_s128");
+            return SGLK_OK;
+        }
+    }
+#undef SGLK_LAUNCH_S128_I8ABL
 #else
 #define SGLK_LAUNCH_S128_B(M_, N_) SGLK_LAUNCH_S128(M_, N_, 0)
 #endif

@@ -81,6 +81,14 @@ struct A8GemmParams {
     int out_s_stride;
     const float* topk_weights;    // DOWN
     int max_mtiles;               // s128 kernel: entries of tile_info that may be read (the launch's m-tile bound)
+    // s128 kernel, int8 W8A8 (terms = 0): x / ic1 rows are int8 in natural k order, w = pack.hip's int8 tiles, w_scale = per weight
+    // row [E][scale_rows]; one f32 factor per x row instead of xs; GATE_UP writes int8 ic1 + out_scale_f32[position] and needs
+    // row_amax [M * topk] (zeroed) and arrivals [max_mtiles] (zeroed) for the per-token maximum across the m-tile's workgroups
+    const float* x_scale_f32;
+    float* out_scale_f32;
+    unsigned* row_amax;
+    int* arrivals;
+    float quant_floor;
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
 int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
@@ -89,7 +97,8 @@ int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStrea
 int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
 // the same contract on 128-token tiles, four waves, two workgroups per CU, weights streamed global -> VGPR
 // (moe_gemm_fp8w_s128.hip); tile table built with tile_m = 128; GATE_UP n_tiles = N / 128, DOWN n_tiles = K / 256
-// terms = 2: x / ic1 rows are the two-term split (above); terms = 1: the a8 mode's quantised rows (moe_gemm_a8.hip's formats)
+// terms = 2: x / ic1 rows are the two-term split (above); terms = 1: the a8 mode's quantised rows (moe_gemm_a8.hip's formats);
+// terms = 0: the int8 W8A8 operator (int8 rows, per-row f32 factors; see A8GemmParams)
 int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream, int terms = 2);
 bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n);
 int launch_split_fp8_block128(const uint16_t* x, int64_t x_stride, uint8_t* q, int64_t q_stride, uint8_t* s, int64_t s_stride,

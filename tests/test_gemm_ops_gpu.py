@@ -98,6 +98,42 @@ def test_fused_experts_int8_on_int8_mfma(ops, shape):
     assert torch.equal(out, again), "run-to-run bit identity"
 
 
+@pytest.mark.parametrize("shape", [(1024, 768, 2048, 16, 4), (1000, 256, 512, 4, 2), (3000, 384, 1024, 32, 8), (4096, 768, 2048, 128, 8),
+                                   (16384, 768, 2048, 128, 8)], ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_int8_on_the_128_token_kernel(ops, knob, shape):
+    """Large-M int8 fused_experts on moe_gemm_fp8w_s128.hip (terms = 0, the default): exact int32 sums on mfma_i32_32x32x32_i8,
+    silu(gate) * up quantised per token inside GEMM-1's epilogue (row maxima exchanged between the m-tile's workgroups).  Same
+    arithmetic as gemm_i8_256.hip + the separate quantisation pass: BIT-IDENTICAL to that path (SGLK_I8_S128=0), ragged expert
+    loads, masked slots and Qwen3-30B-A3B expert dims at 4096 / 16384 tokens (bench_moe.py:89-106) included; the small shapes
+    also against the oracle with the reference's bars (test_moe_int8.py:134-137)."""
+    from sgl_kernel import _lib, _ops
+    M, N, K, E, topk = shape
+    inp = recipes.moe_int8_inputs(M, N, K, E, topk, 4200 + M)
+    ids = inp["topk_ids"].clone()
+    ids[::7, 0] = -1
+    d = cuda(inp)
+    idc = ids.cuda()
+    w1p, w2p = ops.convert_weight_packed(d["w1"]), ops.convert_weight_packed(d["w2"])
+    call = lambda: ops.fused_experts_cpu(d["a"].clone(), w1p, w2p, d["topk_weight"], idc, False, True, False, d["w1s"], d["w2s"],
+                                         None, None, None, True)
+    knob(SGLK_I8_S128=1)
+    out = call()
+    assert (_ops.last_path & _lib.PATH_TILE_MASK) == 128
+    assert torch.equal(out, call()), "run-to-run bit identity"
+    knob(SGLK_I8_S128=0)
+    out256 = call()
+    assert (_ops.last_path & _lib.PATH_TILE_MASK) == 256
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, out256), "128-token int8 kernel != 256-row int8 kernels"
+    if M <= 4096:
+        sel = torch.arange(0, M, max(1, M // 256))
+        ref = moe.fused_experts_int8(inp["a"][sel], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], inp["topk_weight"][sel], ids[sel]).float()
+        o = out[sel].float().cpu()
+        mre = (o - ref).abs().mean() / ref.abs().mean()
+        assert mre < 0.01, f"mean relative error {mre:.4f}"
+        assert ref_pred(ref, out[sel])
+
+
 @pytest.mark.parametrize("shape", [(200, 768, 2048, 16, 4), (4, 384, 1024, 32, 8), (150, 384, 640, 8, 2), (61, 256, 4352, 4, 2),
                                    (300, 256, 512, 8, 2)], ids=lambda s: "x".join(map(str, s)))
 def test_fused_experts_int8_on_mid_kernel(ops, shape):

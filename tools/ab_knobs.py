@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--fp8-act", action="store_true", help="opt-in a8 mode for every variant")
+    ap.add_argument("--int8", action="store_true", help="the int8 W8A8 operator (bench_moe.py:89-106) instead of fp8 W8A16")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
     variants = []
@@ -46,6 +47,13 @@ def main():
         _ops.set_fp8_activations(True)
     for M in [int(x) for x in args.tokens.split(",")]:
         a, w1, w2, w1s, w2s, tw, ids = bench.make_inputs(M, bench.N_EXPERTS, dev, 1111)
+        if args.int8:
+            g = torch.Generator(device=dev).manual_seed(77)
+            E, N2, K = w1.shape
+            w1 = torch.randint(-127, 128, w1.shape, generator=g, dtype=torch.int8, device=dev)
+            w2 = torch.randint(-127, 128, w2.shape, generator=g, dtype=torch.int8, device=dev)
+            w1s = torch.rand(E, N2, generator=g, device=dev) * 1e-2
+            w2s = torch.rand(E, K, generator=g, device=dev) * 1e-2
         w1p = [ops.convert_weight_packed(w1)]
         w2p = [ops.convert_weight_packed(w2)]
         del w1, w2
@@ -54,6 +62,9 @@ def main():
         inputs = [a.clone() for _ in range(args.iters)]
 
         def call(i):
+            if args.int8:
+                return ops.fused_experts_cpu(inputs[i % len(inputs)], w1p[i & 1], w2p[i & 1], tw, ids, False, True, False, w1s, w2s,
+                                             None, None, None, True)
             return ops.fused_experts_cpu(inputs[i % len(inputs)], w1p[i & 1], w2p[i & 1], tw, ids, False, False, True, w1s, w2s,
                                          bench.BLOCK, None, None, True)
 

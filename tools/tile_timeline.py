@@ -20,6 +20,12 @@ tw, ids = torch.topk(torch.softmax(torch.randn(M, E, device="cuda", generator=g)
 dbg = torch.zeros(2 * 32 * 16384, dtype=torch.int64, device="cuda")
 os.environ["SGLK_DBG_PTR"] = hex(dbg.data_ptr())
 f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, True, w1s, w2s, [128, 128], None, None, True)
+if os.environ.get("SGLK_TL_INT8"):   # the int8 W8A8 operator on the same kernels
+    w1 = ops.convert_weight_packed(torch.randint(-127, 128, (E, 2 * N, K), device="cuda", generator=g, dtype=torch.int8))
+    w2 = ops.convert_weight_packed(torch.randint(-127, 128, (E, K, N), device="cuda", generator=g, dtype=torch.int8))
+    w1s = torch.rand(E, 2 * N, device="cuda", generator=g) * 1e-2
+    w2s = torch.rand(E, K, device="cuda", generator=g) * 1e-2
+    f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, True, False, w1s, w2s, None, None, None, True)
 t0 = time.time()
 while time.time() - t0 < 2.0:
     for _ in range(50): f()
@@ -33,6 +39,11 @@ for name, full in (("GEMM-1", both[0]), ("GEMM-2", both[1])):
     us = lambda x: x / 100.0
     print(f"{name}: {len(full)} workgroups; kernel span {us(ack.max() - entry.min()):.1f} us")
     e1, e2, e3 = full[:, 25], full[:, 26], full[:, 27]
+    if (full[:, 28] > 0).any():   # int8 GEMM-1: the row-maximum exchange between the m-tile's workgroups
+        x1, x2, x3 = full[:, 28], full[:, 29], full[:, 30]
+        for lab, v in (("  epi: barrier 1 -> maxima posted", x1 - e1), ("  epi: arrival + wait", x2 - x1), ("  epi: maxima read back", x3 - x2),
+                       ("  epi: quantise -> image written", e2 - x3)):
+            print(f"   {lab:40s} median {v.median() / 100.0:7.2f} us   p10 {v.quantile(0.1) / 100.0:7.2f}   p90 {v.quantile(0.9) / 100.0:7.2f}")
     for lab, v in (("  epi: loop end -> barrier 1", e1 - l1), ("  epi: image written by wave 0", e2 - e1), ("  epi: barrier 2", e3 - e2),
                    ("  epi: rows read + stores issued", st - e3), ("prologue (entry -> loop)", l0 - entry), ("main loop", l1 - l0), ("epilogue (loop end -> stores issued)", st - l1),
                    ("store ack", ack - st), ("whole workgroup", ack - entry)):
