@@ -19,12 +19,16 @@
 //     they do after finishing call e -- so nobody overwrites a buffer that is still being read, without a trailing barrier.
 #include <string.h>
 
+#include "knobs.h"
 #include "sglk_common.h"
 
 namespace sglk {
 
 constexpr int kMaxRanks = 8;
-constexpr long long kWaitTicks = 200000000ll;   // wall_clock64() runs at 100 MHz: give up after 2 s
+// wall_clock64() runs at 100 MHz.  A consumer gives up on a peer after knobs().ar_wait_ms (SGLK_AR_WAIT_MS, default 30 s: a first
+// call's warm-up, a garbage-collection pause or a slow peer are not failures; a collective library would wait for ever, a
+// kernel must not), sets the status word and leaves `out` unwritten: the caller sees the status at its next call
+// (collectives.py) and has to resynchronise the group before using the communicator again.
 
 struct CommView {
     unsigned char* data[kMaxRanks];   // each rank's staging region: [2 parities][2 areas: input copy, reduced slices][cap bytes]
@@ -42,6 +46,9 @@ SGLK_DEV u32x4 ld_sys(const unsigned char* area, unsigned bytes, unsigned off) {
 
 __global__ __launch_bounds__(256) void ar_copy_kernel(const uint4* __restrict__ in, uint4* __restrict__ dst, long long n16) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = in[i];
+    // the staging area is ordinary (coarse-grained) device memory that PEERS read: make this thread's stores visible at system
+    // scope before the kernel ends, rather than relying on the end-of-kernel write-back alone
+    __threadfence_system();
 }
 
 // one thread: tell every rank (myself included) that my step `phase` of call `epoch` is complete
@@ -51,7 +58,7 @@ __global__ void ar_signal_kernel(CommView c, int phase, unsigned epoch) {
 }
 
 // every rank's flag for `phase` has reached `epoch` (one lane per workgroup polls; bounded)
-SGLK_DEV bool wait_all(const CommView& c, int phase, unsigned epoch, int* status) {
+SGLK_DEV bool wait_all(const CommView& c, int phase, unsigned epoch, int* status, long long wait_ticks) {
     __shared__ int ok_s;
     if (threadIdx.x == 0) {
         int ok = 1;
@@ -60,7 +67,7 @@ SGLK_DEV bool wait_all(const CommView& c, int phase, unsigned epoch, int* status
             const long long t0 = wall_clock64();
             // epochs only grow; the subtraction handles wrap-around
             while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
-                if (wall_clock64() - t0 > kWaitTicks) { ok = 0; break; }
+                if (wall_clock64() - t0 > wait_ticks) { ok = 0; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
         }
@@ -87,8 +94,9 @@ SGLK_DEV u32x4 pack8(const float* acc) {
 
 // out[i] = bf16(sum over ranks r ascending of copy_r[i]) for 16-byte chunks [c0, c1)
 __global__ __launch_bounds__(256) void ar_reduce_kernel(CommView c, long long area_off, long long c0, long long c1,
-                                                        uint4* __restrict__ out, long long out_c0, unsigned epoch, int* status) {
-    if (!wait_all(c, 0, epoch, status)) return;
+                                                        uint4* __restrict__ out, long long out_c0, unsigned epoch, int* status,
+                                                        long long wait_ticks) {
+    if (!wait_all(c, 0, epoch, status, wait_ticks)) return;
     for (long long i = c0 + (long long)blockIdx.x * 256 + threadIdx.x; i < c1; i += (long long)gridDim.x * 256) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         u32x4 v[kMaxRanks];
@@ -101,12 +109,13 @@ __global__ __launch_bounds__(256) void ar_reduce_kernel(CommView c, long long ar
         const u32x4 o = pack8(acc);
         out[i - c0 + out_c0] = make_uint4(o[0], o[1], o[2], o[3]);
     }
+    __threadfence_system();   // two-shot: `out` is my reduced area, which the peers gather (see ar_copy_kernel)
 }
 
 // two-shot, second half: out[slice r] = rank r's reduced slice
 __global__ __launch_bounds__(256) void ar_gather_kernel(CommView c, long long area_off, long long per, long long n16,
-                                                        uint4* __restrict__ out, unsigned epoch, int* status) {
-    if (!wait_all(c, 1, epoch, status)) return;
+                                                        uint4* __restrict__ out, unsigned epoch, int* status, long long wait_ticks) {
+    if (!wait_all(c, 1, epoch, status, wait_ticks)) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / per);
         const u32x4 v = ld_sys(c.data[r] + area_off, (unsigned)c.cap, (unsigned)((i - (long long)r * per) * 16));
@@ -188,19 +197,20 @@ extern "C" int sglk_allreduce_sum_bf16(void* const* peer_data, void* const* peer
                                                                               // starve the kernels it is waiting for
     // two-shot when slices are whole 16-byte chunks and the message is large (algo: 0 = by size, 1 = one-shot, 2 = two-shot)
     const bool two = algo == 2 || (algo == 0 && world > 2 && n_elems * 2 >= (1 << 20));
+    const long long wait_ticks = (long long)(knobs().ar_wait_ms > 0 ? knobs().ar_wait_ms : 30000) * 100000ll;
     hipLaunchKernelGGL(ar_copy_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)in, (uint4*)(c.data[rank] + in_area), n16);
     hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, s, c, 0, epoch);
     if (!two) {
-        hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, c, in_area, 0ll, n16, (uint4*)out, 0ll, epoch, status_dev);
+        hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, c, in_area, 0ll, n16, (uint4*)out, 0ll, epoch, status_dev, wait_ticks);
     } else {
         const long long per = ceil_div(n16, world);
         const long long c0 = (long long)rank * per < n16 ? (long long)rank * per : n16;
         const long long c1 = c0 + per < n16 ? c0 + per : n16;
         // my slice of the sum -> my reduced area (position 0 of it), then publish; then gather everybody's slice
         hipLaunchKernelGGL(ar_reduce_kernel, dim3(blocks), dim3(256), 0, s, c, in_area, c0, c1, (uint4*)(c.data[rank] + red_area), 0ll,
-                           epoch, status_dev);
+                           epoch, status_dev, wait_ticks);
         hipLaunchKernelGGL(ar_signal_kernel, dim3(1), dim3(64), 0, s, c, 1, epoch);
-        hipLaunchKernelGGL(ar_gather_kernel, dim3(blocks), dim3(256), 0, s, c, red_area, per, n16, (uint4*)out, epoch, status_dev);
+        hipLaunchKernelGGL(ar_gather_kernel, dim3(blocks), dim3(256), 0, s, c, red_area, per, n16, (uint4*)out, epoch, status_dev, wait_ticks);
     }
     SGLK_CHECK_LAUNCH("allreduce");
     return SGLK_OK;

@@ -62,7 +62,12 @@ int pick_tile_m(int M, int N, int K, int E, int topk, int block_n, int64_t hidde
     // kernel's DOWN stage is thousands of workgroups with a three-block reduction each, and the 256-row kernel wins from ~72 rows on
     // (tools/ab_moe_shapes.py, profiles/r02_ab_moe_shapes.txt: N = 384, K = 7168, E = 256 at 123 rows per expert -- the reference
     // bench's own shape, bench_moe.py:144-145 -- 1.14 -> 0.94 ms)
-    const int64_t lo = kn.mid_lo, hi = kn.mid_hi > 0 ? kn.mid_hi : ((N <= 512 && K >= 4096) ? 72 : 160);
+    // With the 128-token two-workgroups-per-CU kernel behind the "256" answer (moe_gemm_fp8w_s128.hip: one tile per expert at 128
+    // rows, token tiles without rows skipped) the crossover sits at ~64 rows per expert: M = 1024 / 1536 / 2048 at Qwen3 dims
+    // 419 -> 432 / 464 -> 559 / 519 -> 591 TFLOP/s (profiles/r03_ab_mid_vs_s128.txt)
+    const bool s128_next = ok256 && moe_gemm_fp8w_s128_ok(N, K, block_n) && (kn.s128 >= 0 ? kn.s128 == 1 : (kS128Default && kn.split < 0)) &&
+                           (int64_t)M * K * 2 < (1ll << 32) && S * (int64_t)N * 2 < (1ll << 32);
+    const int64_t lo = kn.mid_lo, hi = kn.mid_hi > 0 ? kn.mid_hi : (s128_next ? 64 : ((N <= 512 && K >= 4096) ? 72 : 160));
     if (ok_stream && S < lo * E) return kStreamTileM;
     if (ok_mid && S < hi * E) return kMidTileM;
     if (ok_stream && !ok_mid && S < (int64_t)44 * E) return kStreamTileM;
@@ -244,8 +249,10 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     }
     SGLK_REQUIRE(((uintptr_t)a->out % 2) == 0 && ((uintptr_t)a->hidden % 2) == 0, SGLK_ERR_INVALID, "fused_experts: misaligned");
 
-    SGLK_REQUIRE((a->flags & ~SGLK_MOE_FP8_ACT) == 0, SGLK_ERR_INVALID, "fused_experts: unknown flags 0x%x", a->flags);
-    const Workspace w = plan_workspace(M, N, K, E, topk, a->wtype, a->flags);
+    // SGLK_MOE_PACK_WEIGHTS is a hint: when the re-tiled copy was not made above (weights already packed, M == 0, a shape the
+    // tuned kernels do not take, a workspace sized without the flag) the call runs on the weights as given
+    SGLK_REQUIRE((a->flags & ~(SGLK_MOE_FP8_ACT | SGLK_MOE_PACK_WEIGHTS)) == 0, SGLK_ERR_INVALID, "fused_experts: unknown flags 0x%x", a->flags);
+    const Workspace w = plan_workspace(M, N, K, E, topk, a->wtype, a->flags & ~SGLK_MOE_PACK_WEIGHTS);   // (the copy is the plan's last region)
     SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "fused_experts: workspace %zu < required %zu",
                  a->workspace_bytes, w.total);
     SGLK_REQUIRE(((uintptr_t)a->workspace % 256) == 0, SGLK_ERR_INVALID, "fused_experts: workspace must be 256-B aligned");
@@ -268,10 +275,10 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     const bool tuned = tuned_fp8_ok(a);
     const bool a8 = (a->flags & SGLK_MOE_FP8_ACT) != 0;
     if (a8) {   // an explicit request: refuse what the a8 kernels cannot take instead of answering with other numerics
-        SGLK_REQUIRE(tuned && K % 256 == 0 && N % 128 == 0 && N >= 256 && a->block_n % 32 == 0 && K <= 4096 && N <= 4096 &&
+        SGLK_REQUIRE(tuned && K % 256 == 0 && N % 128 == 0 && N >= 256 && a->block_n % 32 == 0 && K <= 8192 && N <= 8192 &&
                          (int64_t)M * K < (1ll << 32) && (int64_t)M * topk * N < (1ll << 32) && (int64_t)2 * N * K < (1ll << 32),
                      SGLK_ERR_SHAPE, "fused_experts: SGLK_MOE_FP8_ACT needs packed fp8 weights, block [32k,128], K %% 256 == 0, "
-                     "N %% 128 == 0, K,N <= 4096 (got N=%d K=%d block_n=%d packed=%d)", N, K, a->block_n, a->packed);
+                     "N %% 128 == 0, K,N <= 8192 (got N=%d K=%d block_n=%d packed=%d)", N, K, a->block_n, a->packed);
     }
     const bool mid_i8 = mid_int8_ok(a);
     const bool tuned_i8 = !mid_i8 && tuned_int8_ok(a);
@@ -287,6 +294,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     if (s128) tile_m = 128;
     const bool a8s = a8 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (knobs().a8_s128 >= 0 ? knobs().a8_s128 == 1 : kA8S128Default);
     if (a8s) tile_m = 128;
+    SGLK_REQUIRE(!a8 || a8s || (K <= 4096 && N <= 4096), SGLK_ERR_SHAPE, "fused_experts: the 256-row a8 kernels (SGLK_A8_S128=0) take K, N <= 4096");
     const bool i8s = tuned_i8 && moe_gemm_fp8w_s128_ok(N, K, 32) && (knobs().i8_s128 >= 0 ? knobs().i8_s128 == 1 : kI8S128Default);
     if (i8s) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
@@ -364,6 +372,9 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         sjob.cols = K;
         sjob.terms = 0;
     }
+    // the one-launch router + align does not clear the persistent kernels' tile tickets (moe_align's launches do)
+    if (routed_and_aligned && tile_m == 256 && hipMemsetAsync(ws + w.tickets, 0, 16 * sizeof(int), s) != hipSuccess)
+        SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: ticket reset failed");
     if (!routed_and_aligned && !inline_align)
         rc = launch_moe_align_split(a->topk_ids, M, E, topk, tile_m, sorted_slot, expert_off, tile_info, num_tiles,
                                     split_tails ? kMidTileM : 0, tile_info_b, num_tiles_b, ws + w.align_ws,

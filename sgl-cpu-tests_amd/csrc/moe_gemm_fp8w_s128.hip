@@ -41,13 +41,14 @@ namespace gs128 {
 constexpr int kBM = 128;
 constexpr int kStageX = kBM * 128;            // 16 KiB: 128 tokens x (hi 64 + lo 64) bytes
 constexpr int kRing = 4;
-constexpr int kMaxKB = 32;                    // reduction length <= 4096
+constexpr int kMaxKB = 64;                    // reduction length <= 8192
 constexpr int kImage = 64 * 1024;             // the ring (4 x 16 KiB) = the DOWN epilogue image (128 rows x 512 B)
-constexpr int kScaleOff = kImage;                         // sc[16 pieces][kMaxKB] f32 (2 KiB)
-constexpr int kXsOff = kScaleOff + 16 * kMaxKB * 4;       // xs[kb][128 tokens] E8M0 bytes (4 KiB)
+constexpr int kScaleOff = kImage;                         // sc[16 pieces][kMaxKB] f32 (4 KiB)
+constexpr int kXsOff = kScaleOff + 16 * kMaxKB * 4;       // xs[kb][128 tokens] E8M0 bytes (8 KiB)
 constexpr int kRowTabOff = kXsOff + kMaxKB * kBM;         // DOWN: output slot + routing weight per tile row (1 KiB)
 constexpr int kAmaxOff = kRowTabOff + 2 * kBM * 4;        // GATE_UP epilogue: amax[4 waves][128] f32 (2 KiB)
-constexpr int kLds = kAmaxOff + 4 * kBM * 4;              // 73 KiB: two workgroups per CU
+constexpr int kLds = kAmaxOff + 4 * kBM * 4;              // 79 KiB: two workgroups per CU
+constexpr int kScPer = 16 * kMaxKB / 256;                 // scale-table entries a thread fetches
 
 // s_waitcnt immediate (gfx9 encoding): vmcnt in bits 3:0 and 15:14, expcnt 6:4 (7 = no wait), lgkmcnt 11:8 (15 = no wait)
 constexpr int wc(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
@@ -137,15 +138,15 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     const int xo_l0 = r32 * kXB + (((4 + 2 * h) ^ sw) << 4), xo_l1 = r32 * kXB + (((5 + 2 * h) ^ sw) << 4);   // two terms only
 
     // ---- prologue loads (parked in registers; written to the LDS tables after the first operand loads have been issued) ----
-    float sc_reg[2] = {0.f, 0.f};
+    float sc_reg[kScPer] = {};
     if (I8) {   // per-weight-row factors of the workgroup's 256 rows: sc[piece * 16 + row of the piece]
         sc_reg[0] = p.w_scale[(int64_t)cur.e * p.scale_rows + piece_row16(tid >> 4) * 16 + (tid & 15)];
     } else {
         const float* scale_e = p.w_scale + (int64_t)cur.e * p.scale_rows * p.scale_cols;
         const float inv_bn = 1.0f / (float)p.block_n;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + j * 256, piece = i >> 5, kb = i & (kMaxKB - 1);
+        for (int j = 0; j < kScPer; ++j) {
+            const int i = tid + j * 256, piece = i / kMaxKB, kb = i & (kMaxKB - 1);
             sc_reg[j] = 0.f;
             if (kb < kblocks) {
                 // floor(row / block_n) through one float multiply (exact for rows < 2^20, see moe_gemm_fp8w_256i.hip)
@@ -248,7 +249,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         issue_x(3, 3, 1);
     }
     sc[tid] = sc_reg[0];
-    if (!I8) sc[tid + 256] = sc_reg[1];
+    if (!I8) {
+#pragma unroll
+        for (int j = 1; j < kScPer; ++j) sc[tid + j * 256] = sc_reg[j];
+    }
     if (tid < kBM) {
         if (I8) {
             reinterpret_cast<float*>(xs_tab)[tid] = xs_f32;

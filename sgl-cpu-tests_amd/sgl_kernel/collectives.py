@@ -18,7 +18,17 @@ class XgmiAllReduce:
     """Direct all-reduce between the GPUs of one node over xGMI peer memory (sglk_allreduce_sum_bf16, include/sglk.h): every
     rank maps its peers' staging regions through HIP IPC; one-shot for small messages, two-shot (reduce-scatter + all-gather of
     slices) for large ones, fp32 sums in ascending rank order -- bit-identical on every rank.  The 64-byte IPC handles travel
-    through the torch.distributed group once, at construction; no collective of the group is used afterwards."""
+    through the torch.distributed group once, at construction; no collective of the group is used afterwards.
+
+    Status: exercised with 2 and 4 processes SHARING one GPU (tests/test_xgmi_allreduce_gpu.py); NOT yet run across the GPUs of a
+    node (no 8-GPU box in this build's reach), so the cross-GPU visibility of the staged data -- system-scope fences at the end of
+    the producing kernels + sc0 sc1 loads in the consumers -- is unverified there.  Opt-in for that reason: nothing uses it
+    unless the caller constructs one.
+
+    Failure model: a rank that waits longer than SGLK_AR_WAIT_MS (default 30 s) for a peer gives up, leaves its output unwritten
+    and sets a status word.  `all_reduce` / `shm_allreduce` read a host mirror of that word at the NEXT call (no stream
+    synchronisation) and raise; `check()` synchronises and raises at once.  After a failure the ranks' epochs are out of step:
+    every rank calls `resync()` (a collective on the group) before the communicator is used again."""
 
     def __init__(self, group=None, max_bytes=16 << 20, register=True):
         import ctypes
@@ -53,33 +63,53 @@ class XgmiAllReduce:
             self._opened += [od.value, of.value]
         self._pd, self._pf = pd, pf
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._host_status = torch.zeros(1, dtype=torch.int32).pin_memory()   # mirror, refreshed behind every call (async copy)
         self.epoch = 0
         dist.barrier(group=group)          # everybody has mapped everybody before the first call
         if register:
             _xgmi[group] = self
 
     def supports(self, t):
-        return t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0 and \
-            t.numel() * 2 <= self.cap and t.data_ptr() % 16 == 0
+        """Decided from what every rank sees alike (device kind, dtype, element count): ranks must never split between this path
+        and torch.distributed for one call.  Layout and alignment are local properties -- all_reduce stages such tensors."""
+        return t.is_cuda and t.dtype == torch.bfloat16 and t.numel() % 8 == 0 and t.numel() * 2 <= self.cap
 
     def all_reduce(self, t, algo=0):
         """In-place sum over the ranks (bf16).  algo: 0 by size, 1 one-shot, 2 two-shot."""
         if not self.supports(t):
-            raise RuntimeError("XgmiAllReduce: contiguous 16-byte aligned bf16 CUDA tensors of a multiple of 8 elements, "
-                               f"at most {self.cap} bytes")
+            raise RuntimeError(f"XgmiAllReduce: bf16 CUDA tensors of a multiple of 8 elements, at most {self.cap} bytes")
+        if int(self._host_status[0]) != 0:      # an earlier call gave up on a peer (mirror of the device word; no synchronisation)
+            raise RuntimeError("XgmiAllReduce: a peer did not arrive within SGLK_AR_WAIT_MS in an earlier call; that call's output "
+                               "was not written.  Call resync() on every rank of the group before using the communicator again")
+        work = t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.contiguous().clone()   # clone(): a fresh, aligned block
         self.epoch += 1
         ct = self._ct
+        stream = torch.cuda.current_stream(t.device)
         self._lib.check(self._lib.lib().sglk_allreduce_sum_bf16(
-            self._pd, self._pf, self.rank, self.world, self.cap, ct.c_void_p(t.data_ptr()), ct.c_void_p(t.data_ptr()), t.numel(),
-            self.epoch & 0xFFFFFFFF, algo, ct.c_void_p(self.status.data_ptr()),
-            ct.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), "allreduce_sum_bf16")
+            self._pd, self._pf, self.rank, self.world, self.cap, ct.c_void_p(work.data_ptr()), ct.c_void_p(work.data_ptr()), work.numel(),
+            self.epoch & 0xFFFFFFFF, algo, ct.c_void_p(self.status.data_ptr()), ct.c_void_p(stream.cuda_stream)), "allreduce_sum_bf16")
+        self._host_status.copy_(self.status, non_blocking=True)
+        if work is not t:
+            t.copy_(work)
         return t
 
     def check(self):
-        """Synchronises; raises if a peer failed to arrive in some call since the last check."""
+        """Synchronises; raises if a peer failed to arrive in some call since the last check / resync."""
         if int(self.status.item()) != 0:
-            self.status.zero_()
-            raise RuntimeError("XgmiAllReduce: a peer did not arrive within the spin limit")
+            raise RuntimeError("XgmiAllReduce: a peer did not arrive within SGLK_AR_WAIT_MS; call resync() on every rank")
+
+    def resync(self):
+        """Collective on the group, after a failed call: drains this rank's stream, moves every rank to one common epoch above
+        all epochs in use (the flag words only ever grow, so nothing has to be cleared) and clears the status."""
+        torch.cuda.synchronize()
+        on_gpu = dist.get_backend(self.group) != "gloo"
+        e = torch.tensor([self.epoch], dtype=torch.int64, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX, group=self.group)
+        self.epoch = int(e.item()) + 2
+        self.status.zero_()
+        self._host_status.zero_()
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)
 
     def close(self):
         """Collective: every rank unmaps its peers and frees its own regions.  The barrier keeps a fast rank from freeing memory

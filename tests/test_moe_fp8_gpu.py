@@ -241,6 +241,45 @@ def test_fused_experts_fp8_rowmajor_weights_are_retiled_at_prefill_sizes(ops):
         check_close(rowmajor, ref, f"row-major M={M}")
 
 
+def test_pack_weights_flag_is_a_hint(ops):
+    """C-ABI: SGLK_MOE_PACK_WEIGHTS on a call that cannot use it -- weights already packed, a workspace sized WITHOUT the flag
+    (sglk_fused_experts_workspace_bytes), M == 0 -- runs on the weights as given instead of failing with "unknown flags"
+    (ADVICE r2)."""
+    import ctypes
+    from sgl_kernel import _lib
+    L = _lib.lib()
+    M, N, K, E, topk, bn, bk = 96, 256, 512, 8, 2, 128, 128
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 6200)
+    ref_out, d = run_fp8(ops, inp, (bn, bk))
+    w1p, w2p = ops.convert_weight_packed(d["w1"]), ops.convert_weight_packed(d["w2"])
+    tw, ids = d["topk_weight"].float().contiguous(), d["topk_ids"].int().contiguous()
+    w1s, w2s = d["w1s"].float().contiguous(), d["w2s"].float().contiguous()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(m, w1, w2, packed, ws_bytes):
+        out = torch.zeros(max(m, 1), K, dtype=torch.bfloat16, device="cuda")
+        ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device="cuda")
+        args = _lib.FusedExpertsArgs(
+            hidden=d["a"].data_ptr(), hidden_stride=K, out=out.data_ptr(), out_stride=K, w1=w1.data_ptr(), w2=w2.data_ptr(),
+            w1_scale=w1s.data_ptr(), w2_scale=w2s.data_ptr(), topk_weights=tw.data_ptr(), topk_ids=ids.data_ptr(),
+            M=m, N=N, K=K, E=E, topk=topk, wtype=_lib.W_FP8_E4M3, packed=packed, block_n=bn, block_k=bk,
+            workspace=ws.data_ptr(), workspace_bytes=ws_bytes, stage_timer=None, aux_stream=None,
+            aux_events=(ctypes.c_void_p * 2)(), flags=_lib.MOE_PACK_WEIGHTS, path_taken=None)
+        rc = L.sglk_fused_experts(ctypes.byref(args), stream)
+        torch.cuda.synchronize()
+        return rc, out
+
+    small = L.sglk_fused_experts_workspace_bytes(M, N, K, E, topk, _lib.W_FP8_E4M3)
+    rc, out = call(M, w1p, w2p, 3, small)                       # already packed
+    assert rc == 0 and torch.equal(out, ref_out)
+    rc, out = call(M, d["w1"], d["w2"], 0, small)               # row-major, but no room for the re-tiled copy: generic engine
+    assert rc == 0
+    check_close(out, moe.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"],
+                                           inp["topk_ids"]), "row-major, workspace without room for the copy")
+    rc, _ = call(0, d["w1"], d["w2"], 0, small)                 # nothing to do
+    assert rc == 0
+
+
 @pytest.mark.parametrize("M,topk,masked", [(1, 8, False), (3, 8, True), (4, 8, False), (4, 8, True), (16, 2, True), (32, 1, False)])
 def test_fused_experts_fp8_decode_sizes_sort_ids_in_the_gemm_kernels(ops, M, topk, masked, knob):
     """At most 32 slots: no moe_align launch, the weight-streaming kernels derive their tile from topk_ids themselves

@@ -77,7 +77,12 @@ def _worker(rank, world, port, ret, stall):
         dist.barrier()
         timed_out = None
         if stall:
-            # a peer that never arrives: the kernels give up after the spin limit and the status word says so (no hang)
+            # a peer that never arrives: the kernels give up after SGLK_AR_WAIT_MS and the status word says so (no hang); the NEXT
+            # call reports it too, unasked (host mirror of the status word); resync() on every rank makes the communicator usable
+            # again
+            from sgl_kernel import _lib
+            os.environ["SGLK_AR_WAIT_MS"] = "1500"
+            _lib.lib().sglk_reload_env()
             if rank == 0:
                 x = torch.ones(8, dtype=torch.bfloat16, device="cuda")
                 comm.all_reduce(x)
@@ -86,7 +91,27 @@ def _worker(rank, world, port, ret, stall):
                     timed_out = False
                 except RuntimeError:
                     timed_out = True
+                try:
+                    comm.all_reduce(x)
+                    timed_out = False
+                except RuntimeError:
+                    pass
             dist.barrier()
+            comm.resync()
+            full = _inputs(world, 4096, 77)
+            t = full[rank].cuda()
+            comm.all_reduce(t)
+            comm.check()
+            checks["after_resync"] = torch.equal(t.cpu(), _expected(full))
+            # a misaligned view on ONE rank: every rank still takes the direct path (the choice is rank-invariant), that rank stages
+            base = torch.zeros(4096 + 8, dtype=torch.bfloat16, device="cuda")
+            v = base[4:4 + 4096] if rank == 0 else base[:4096]
+            v.copy_(full[rank])
+            assert (v.data_ptr() % 16 != 0) == (rank == 0)
+            e0 = comm.epoch
+            ops.shm_allreduce(v, None, dist.ReduceOp.SUM)
+            comm.check()
+            checks["misaligned_on_one_rank"] = torch.equal(v.cpu(), _expected(full)) and comm.epoch == e0 + 1
         ret[rank] = (checks, ms, timed_out)
     finally:
         if comm is not None:

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
 import torch
 import sgl_kernel  # noqa
 ops = torch.ops.sgl_kernel
-K, N, E, topk, M = 2048, 768, 128, 8, 16384
+K, N, E, topk, M = 2048, 768, 128, 8, int(os.environ.get("SGLK_TL_M", "16384"))
 g = torch.Generator(device="cuda").manual_seed(1)
 w1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
 w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
@@ -95,5 +95,17 @@ for name, full in (("GEMM-1", both[0]), ("GEMM-2", both[1])):
         clk = full[:, 0] / full[:, 1].clamp_min(1) * 100.0
         print(f"   in-kernel clock over the main loop: median {clk.median():.0f} MHz (p10 {clk.quantile(0.1):.0f}, p90 {clk.quantile(0.9):.0f})")
     print(f"   per CU: some workgroup in its main loop {cov1.median():.3f} of the busy span (p10 {cov1.quantile(0.1):.3f}); two or more {cov2.median():.3f}")
+    # how the launch ends: when each CU goes idle relative to the last one, and the work (main-loop time) per CU
+    t_end = ack.max()
+    idle, busy = [], []
+    for c in cu.unique():
+        sel = full[cu == c]
+        idle.append(float(t_end - sel[:, 24].max()) / 100.0)
+        busy.append(float((sel[:, 20] - sel[:, 19]).sum()) / 100.0)
+    idle, busy = torch.tensor(idle), torch.tensor(busy)
+    nta = ((full[:, 20] - full[:, 19]) < 0.6 * (l1 - l0).median()).sum()
+    print(f"   end of the launch: a CU is idle for the last {idle.median():.1f} us (median; p90 {idle.quantile(0.9):.1f}, max {idle.max():.1f}) of "
+          f"{us(ack.max() - entry.min()):.1f}; main-loop time per CU min/median/max {busy.min():.0f}/{busy.median():.0f}/{busy.max():.0f} us; "
+          f"{int(nta)} workgroups with a main loop under 0.6 of the median (partial tiles)")
     print(f"   CUs seen {len(per_cu)}, workgroups per CU min/max {min(per_cu)}/{max(per_cu)}; gap between consecutive workgroups on a CU: "
           f"median {us(gaps.median()):.2f} us  p10 {us(gaps.quantile(0.1)):.2f}  p90 {us(gaps.quantile(0.9)):.2f}")
