@@ -62,6 +62,7 @@ void read_env() {
     k.s128 = env_int("SGLK_S128", -1);
     k.a8_s128 = env_int("SGLK_A8_S128", -1);
     k.i8_s128 = env_int("SGLK_I8_S128", -1);
+    k.dense_s128 = env_int("SGLK_DENSE_S128", -1);
     k.ar_wait_ms = env_int("SGLK_AR_WAIT_MS", 0);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);
     k.rescale_ablate = env_int("SGLK_RESCALE", 0);

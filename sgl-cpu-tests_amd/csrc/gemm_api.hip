@@ -9,8 +9,18 @@ using namespace sglk;
 namespace {
 
 struct DenseWs {
-    size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, partial, total;
+    size_t tile_info, num_tiles, ident, ic1, xq, xs, ic1q, ic1s, partial, xsplit, xsplit_s, total;
 };
+
+// dense GEMMs on the 128-token two-workgroups-per-CU kernel (moe_gemm_fp8w_s128.hip, MODE_PLAIN): whole 256-column output tiles,
+// the reduction in whole 128-wide blocks (2 .. 64), and at least two full rounds of its 128 x 256 tiles over the chip's 512
+// workgroup slots -- below that the 256-row kernels' larger tiles win (same-box A/B, profiles/r03_ab_dense_s128.txt:
+// 4096 x 12288 x 2048 fp8 999 -> 1149 TFLOP/s, int8 1731 -> 1970 TOP/s; 4096 x 1536 x 2048 and 4096 x 2048 x 6144 lose 7-33 %)
+bool dense_s128_shape_ok(int M, int N, int K) {
+    const int k = knobs().dense_s128;
+    const int64_t wgs = ceil_div(M, 128) * (int64_t)(N / 256);
+    return k != 0 && (k > 0 ? M >= 128 : wgs >= 1024) && N % 256 == 0 && K % 128 == 0 && K >= 256 && K <= 8192 && !knobs().force_generic;
+}
 
 // the tuned 256-token fp8 kernel (moe_gemm_fp8w_256i.hip) takes a dense [M][C] x [R][C]^T when this holds
 bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int block_k, const void* x, int64_t x_stride) {
@@ -68,7 +78,7 @@ void fill_tuned(MoeGemmParams& g, const void* x, int64_t x_stride, int M, const 
     g.num_tiles = num_tiles;
 }
 
-DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
+DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act, bool fp8_split = false) {
     DenseWs w{};
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -101,6 +111,10 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act) {
             const size_t b1 = (size_t)k1 * M * 2 * N * 4, b2 = (size_t)k2 * M * K * 4;
             w.partial = take(b1 > b2 ? b1 : b2);
         }
+    }
+    if (fp8_split && !need_ic1 && dense_s128_shape_ok(M, N, K)) {   // fp8 W8A16 on the two-term kernel: x as (hi, lo) e4m3 + scale bytes
+        w.xsplit = take((size_t)M * 2 * K);
+        w.xsplit_s = take((size_t)M * align_up(K / 128, 4));
     }
     if (!need_ic1) {   // plain dense GEMM: fp32 partials of the split-K form (small M)
         int ks = generic_ksplit(M, N, K);
@@ -573,7 +587,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
 
 extern "C" size_t sglk_scaled_mm_workspace_bytes(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8) {
     if (M < 0 || N <= 0 || K <= 0) return 0;
-    return plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8).total;
+    return plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8, wtype == SGLK_W_FP8_E4M3 && !x_is_int8).total;
 }
 
 namespace sglk {
@@ -591,7 +605,7 @@ static size_t weight_bytes(int N, int K, int wtype) { return (size_t)N * K * (wt
 extern "C" size_t sglk_scaled_mm_workspace_bytes_ex(int32_t M, int32_t N, int32_t K, int32_t wtype, int32_t x_is_int8,
                                                     int32_t packed) {
     if (M < 0 || N <= 0 || K <= 0) return 0;
-    const size_t base = align_up(plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8).total, 256);
+    const size_t base = align_up(plan_dense(M, N, K, false, wtype == SGLK_W_INT8 && !x_is_int8, wtype == SGLK_W_FP8_E4M3 && !x_is_int8).total, 256);
     return pack_on_the_fly(M, N, K, wtype, packed) ? base + align_up(weight_bytes(N, K, wtype), 256) : base;
 }
 
@@ -610,7 +624,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
                      "scaled_mm: int8 activations need int8 weights and x_scale");
     }
     const bool quant_here = a->wtype == SGLK_W_INT8 && !a->x_is_int8;
-    const DenseWs w = plan_dense(M, N, K, false, quant_here);
+    const DenseWs w = plan_dense(M, N, K, false, quant_here, a->wtype == SGLK_W_FP8_E4M3 && !a->x_is_int8);
     SGLK_REQUIRE(a->workspace_bytes >= w.total, SGLK_ERR_WORKSPACE, "scaled_mm: workspace %zu < required %zu",
                  a->workspace_bytes, w.total);
     if (M == 0) return SGLK_OK;
@@ -638,6 +652,37 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
         const int kt = tuned_fp8_ksplit(M, N, K);
+        // enough rows to fill the chip: the two-term e4m3 split on the scaled fp8 matrix cores, 128-row tiles, two workgroups per CU
+        // (moe_gemm_fp8w_s128.hip, MODE_PLAIN) -- the W8A16 contract with exact products, as in fused_experts
+        if (kt == 1 && w.xsplit && dense_s128_shape_ok(M, N, K) && (int64_t)M * 2 * K < (1ll << 32) && a->block_n % 32 == 0) {
+            const int t128 = (int)ceil_div(M, 128);
+            uint8_t* xq = ws + w.xsplit;
+            uint8_t* xs = ws + w.xsplit_s;
+            const int xs_stride = (int)align_up(K / 128, 4);
+            rc = launch_split_fp8_block128((const uint16_t*)a->x, a->x_stride, xq, 2 * (int64_t)K, xs, xs_stride, M, K, s);
+            if (rc != SGLK_OK) return rc;
+            A8GemmParams q{};
+            q.x = xq;
+            q.x_stride = 2 * (int64_t)K;
+            q.x_bytes = (int64_t)M * 2 * K;
+            q.xs = xs;
+            q.xs_stride = xs_stride;
+            q.topk = 1;
+            q.w = (const uint8_t*)a->w;
+            q.w_expert_stride = (int64_t)N * K;
+            q.w_scale = a->w_scale;
+            q.scale_rows = (int)ceil_div(N, a->block_n);
+            q.scale_cols = K / 128;
+            q.block_n = a->block_n;
+            q.C = K;
+            q.dense_rows = M;
+            q.n_tiles = N / 256;
+            q.out = a->out;
+            q.out_stride = a->out_stride;
+            q.bias = a->bias;
+            q.max_mtiles = t128;
+            return launch_moe_gemm_fp8w_s128(MODE_PLAIN, q, t128, s, 2);
+        }
         if (kt > 1 && w.partial) {   // K ranges as the tile table's "experts", fp32 partials, ordered reduce (+ bias)
             rc = launch_dense_tiles_ksplit(M, 256, kt, tile_info, num_tiles, ident, s);
             if (rc != SGLK_OK) return rc;
@@ -854,6 +899,29 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
             // under-filled launch, long ranges: exact int32 partials per K range.  The int8 tiles are twice as fast, so the partials'
             // round trip only pays below an eighth of the chip (1024 x 2048 x 6144: 0.066 -> 0.051 ms; 2048 x 4096 x 4096 would lose)
             const int kt = tuned_fp8_ksplit(M, N, K, 8);
+            // enough rows to fill the chip: 128-row tiles, two workgroups per CU (moe_gemm_fp8w_s128.hip, MODE_PLAIN, terms = 0); the
+            // same exact int32 sums and the same separately rounded epilogue, bit for bit
+            if (kt == 1 && dense_s128_shape_ok(M, N, K)) {
+                const int t128 = (int)ceil_div(M, 128);
+                A8GemmParams p8{};
+                p8.x = (const uint8_t*)xq;
+                p8.x_stride = xq_stride;
+                p8.x_bytes = (int64_t)M * xq_stride;
+                p8.x_scale_f32 = xs;
+                p8.topk = 1;
+                p8.w = (const uint8_t*)a->w;
+                p8.w_expert_stride = (int64_t)N * K;
+                p8.w_scale = a->w_scale;
+                p8.scale_rows = N;
+                p8.C = K;
+                p8.dense_rows = M;
+                p8.n_tiles = N / 256;
+                p8.out = a->out;
+                p8.out_stride = a->out_stride;
+                p8.bias = a->bias;
+                p8.max_mtiles = t128;
+                return launch_moe_gemm_fp8w_s128(MODE_PLAIN, p8, t128, s, 0);
+            }
             if (kt > 1 && w.partial) {
                 q.K = K / kt;
                 q.N = N;

@@ -40,6 +40,7 @@ struct Knobs {
     int s128 = -1;               // SGLK_S128: 1 / 0 = the split on 128-token tiles with two workgroups per CU (moe_gemm_fp8w_s128.hip) / never; unset = default
     int a8_s128 = -1;            // SGLK_A8_S128: 1 / 0 = the a8 mode on the 128-token kernel (moe_gemm_fp8w_s128.hip, one term) / on moe_gemm_a8.hip
     int ar_wait_ms = 0;          // SGLK_AR_WAIT_MS: how long the direct all-reduce waits for a peer before it gives up (default 30000)
+    int dense_s128 = -1;         // SGLK_DENSE_S128: 0 = dense fp8 / int8 GEMMs never on the 128-token kernel; 1 = from 128 rows; unset = from 1024 of its tiles
     int i8_s128 = -1;            // SGLK_I8_S128: 1 / 0 = large-M int8 W8A8 fused_experts on the 128-token kernel (terms = 0) / on gemm_i8_256.hip
     int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)
     int rescale_ablate = 0;      // SGLK_RESCALE (SGLK_DEV_ABLATE builds only)

@@ -155,13 +155,15 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             }
         }
     }
+    float bias_reg = 0.f;   // PLAIN: the output column's bias -> the (unused) row table's place
+    if (MODE == MODE_PLAIN && p.bias) bias_reg = p.bias[cur.ntile * 256 + tid];
     int my_slot = -1;
     unsigned xs_reg[kMaxKB / 4];
     float xs_f32 = 0.f;   // int8: the token's dequantisation factor
 #pragma unroll
     for (int i = 0; i < kMaxKB / 4; ++i) xs_reg[i] = 0x7f7f7f7fu;
     if (tid < kBM && tid < cur.rows) {
-        const int slot = p.sorted_slot[cur.pos0 + tid];
+        const int slot = MODE == MODE_PLAIN ? 0 : p.sorted_slot[cur.pos0 + tid];   // PLAIN (dense rows): no routing tables
         const int64_t xrow = (MODE == MODE_GATE_UP) ? (int64_t)(slot / p.topk) : (int64_t)(cur.pos0 + tid);
         if (I8) {
             xs_f32 = p.x_scale_f32[xrow];
@@ -266,6 +268,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         }
         if (MODE == MODE_DOWN) slot_tab[tid] = my_slot;
     }
+    if (MODE == MODE_PLAIN) reinterpret_cast<float*>(smem + kRowTabOff)[tid] = bias_reg;
     // X(0) and A(0) have landed; X(1) A(1) X(2) + two pieces of X(3) = 14 operations stay in flight
     // (one term: X(5) A(1) X(6) A(2) X(7) = 14 as well)
     __builtin_amdgcn_s_waitcnt(wc(14, 0));
@@ -655,7 +658,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             }
         }
     } else if constexpr (I8) {
-        // int8 DOWN: ic2[slot] = ((xs * acc) * ws) * topk_w in bf16, the fp8 form's image and stores
+#pragma clang fp contract(off)
+        // int8 DOWN: ic2[slot] = ((xs * acc) * ws) * topk_w in bf16, the fp8 form's image and stores; PLAIN (dense
+        // int8_scaled_mm, /root/reference/test_gemm_int8.py:41-47): out[row] = (xs * acc) * ws + bias, separately rounded (no
+        // mul+add contraction in this block, as in gemm_i8_256.hip)
         constexpr int kRowB = 512;
         const float* ws_tab = sc;
         const float* xs_f = reinterpret_cast<const float*>(xs_tab);
@@ -663,16 +669,20 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         for (int tt = 0; tt < 4; ++tt) {
             const int r = tt * 32 + r32e;
             unsigned char* rowp = smem + r * kRowB;
-            const float tw = tw_tab[r], xs = xs_f[r];
+            const float tw = MODE == MODE_DOWN ? tw_tab[r] : 1.f, xs = xs_f[r];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
                     float o[4];
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (MODE == MODE_PLAIN) b4 = *reinterpret_cast<const float4*>(smem + kRowTabOff + (wn * 64 + rt * 32 + rg * 8 + he * 4) * 4);
+                    const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o[j] = xs * (float)acc[rt][tt][rg * 4 + j] * ws_tab[wpiece0[rt] * 16 + rg * 8 + he * 4 + j];
-                        o[j] *= tw;
+                        if (MODE == MODE_DOWN) o[j] *= tw;
+                        else if (p.bias) o[j] = o[j] + bj[j];   // (without a bias the oracle adds nothing: -0 stays -0)
                     }
                     uint2 val;
                     val.x = pack_bf16x2(o[0], o[1]);
@@ -693,7 +703,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             const int r = idx >> 5, pc = idx & 31, lc = pc ^ (r & 15);
             if (r < cur.rows) {
                 const uint4 val = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
-                *reinterpret_cast<uint4*>(outp + (int64_t)slot_tab[r] * p.out_stride + cur.ntile * 256 + lc * 8) = val;
+                *reinterpret_cast<uint4*>(outp + (int64_t)(MODE == MODE_PLAIN ? cur.pos0 + r : slot_tab[r]) * p.out_stride + cur.ntile * 256 + lc * 8) = val;
             }
         }
     } else if constexpr (MODE == MODE_GATE_UP && TERMS == 1) {
@@ -814,15 +824,22 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         for (int tt = 0; tt < 4; ++tt) {
             const int r = tt * 32 + r32e;
             unsigned char* rowp = smem + r * kRowB;
-            const float tw = tw_tab[r];
+            const float tw = MODE == MODE_DOWN ? tw_tab[r] : 1.f;   // PLAIN (dense fp8_scaled_mm): out[row] = acc * scale + bias
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const float sc_w = mant[rt] * tw;
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) {
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (MODE == MODE_PLAIN) b4 = *reinterpret_cast<const float4*>(smem + kRowTabOff + (wn * 64 + rt * 32 + rg * 8 + he * 4) * 4);
                     uint2 val;
-                    val.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w, acc[rt][tt][rg * 4 + 1] * sc_w);
-                    val.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w, acc[rt][tt][rg * 4 + 3] * sc_w);
+                    if (MODE == MODE_PLAIN) {
+                        val.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w + b4.x, acc[rt][tt][rg * 4 + 1] * sc_w + b4.y);
+                        val.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w + b4.z, acc[rt][tt][rg * 4 + 3] * sc_w + b4.w);
+                    } else {
+                        val.x = pack_bf16x2(acc[rt][tt][rg * 4 + 0] * sc_w, acc[rt][tt][rg * 4 + 1] * sc_w);
+                        val.y = pack_bf16x2(acc[rt][tt][rg * 4 + 2] * sc_w, acc[rt][tt][rg * 4 + 3] * sc_w);
+                    }
                     const int col = wn * 64 + rt * 32 + rg * 8 + he * 4;
                     const int chunk = (col >> 3) ^ (r & 15);
                     *reinterpret_cast<uint2*>(rowp + chunk * 16 + (col & 4) * 2) = val;
@@ -839,7 +856,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             const int r = idx >> 5, pc = idx & 31, lc = pc ^ (r & 15);
             if (r < cur.rows) {
                 const uint4 val = *reinterpret_cast<const uint4*>(smem + r * kRowB + pc * 16);
-                *reinterpret_cast<uint4*>(outp + (int64_t)slot_tab[r] * p.out_stride + cur.ntile * 256 + lc * 8) = val;
+                *reinterpret_cast<uint4*>(outp + (int64_t)(MODE == MODE_PLAIN ? cur.pos0 + r : slot_tab[r]) * p.out_stride + cur.ntile * 256 + lc * 8) = val;
             }
         }
     }
@@ -865,16 +882,40 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8Gemm
     // its gathered rows and the m-tiles of an expert its weights inside one L2.  Workgroups past the last m-tile leave.
     constexpr int kGroup = 8;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int per = kGroup * p.n_tiles;
-    const int gi = j / per, rem = j - gi * per;
-    const int mi = rem / p.n_tiles;
-    const int mt = (gi * 8 + x) * kGroup + mi;
+    int mt;
     TileId t;
-    t.ntile = rem - mi * p.n_tiles;
+    if (MODE == MODE_PLAIN) {
+        // dense rows: super-tiles of 8 m-tiles x up to 8 column tiles (one XCD's 64 resident workgroups share 8 row tiles and
+        // 8 weight tiles instead of 8 and n_tiles), dealt round-robin to the XCDs, column super-tiles fastest so that an XCD's
+        // next super-tile meets the same rows in its L2
+        const int sn = p.n_tiles < 8 ? p.n_tiles : 8;
+        const int nsn = (p.n_tiles + sn - 1) / sn;
+        const int per = kGroup * sn;
+        const int sl = j / per, rem = j - sl * per;
+        const int st = sl * 8 + x;
+        const int sm = st / nsn, sc_ = st - sm * nsn;
+        const int mi = rem / sn;
+        mt = sm * kGroup + mi;
+        t.ntile = sc_ * sn + (rem - mi * sn);
+        if (t.ntile >= p.n_tiles) return;
+    } else {
+        const int per = kGroup * p.n_tiles;
+        const int gi = j / per, rem = j - gi * per;
+        const int mi = rem / p.n_tiles;
+        mt = (gi * 8 + x) * kGroup + mi;
+        t.ntile = rem - mi * p.n_tiles;
+    }
     t.mt = mt;
     t.L = mt * p.n_tiles + t.ntile;
-    const int4 ti = p.tile_info[mt < p.max_mtiles ? mt : 0];
-    if (mt >= p.num_tiles[0]) return;
+    int4 ti;
+    if (MODE == MODE_PLAIN) {   // dense rows: m-tile mt = rows [128 mt, 128 mt + 128) of p.dense_rows, no table
+        if (mt >= p.max_mtiles) return;
+        const int left = p.dense_rows - mt * kBM;
+        ti = make_int4(0, mt * kBM, left < kBM ? left : kBM, 0);
+    } else {
+        ti = p.tile_info[mt < p.max_mtiles ? mt : 0];
+        if (mt >= p.num_tiles[0]) return;
+    }
     t.e = __builtin_amdgcn_readfirstlane(ti.x);
     t.pos0 = __builtin_amdgcn_readfirstlane(ti.y);
     t.rows = __builtin_amdgcn_readfirstlane(ti.z);
@@ -898,7 +939,11 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
     if ((int64_t)max_mtiles * p.n_tiles == 0) return SGLK_OK;
     // groups of 8 m-tiles dealt round-robin to the 8 XCDs (see the kernel): every XCD gets the same number of workgroups
     const int64_t groups = ceil_div(max_mtiles, 8), groups_per_xcd = ceil_div(groups, 8);
-    const int64_t blocks = groups_per_xcd * 8 * p.n_tiles * 8;
+    int64_t blocks = groups_per_xcd * 8 * p.n_tiles * 8;
+    if (mode == MODE_PLAIN) {   // dense rows: super-tiles of 8 m-tiles x sn column tiles, dealt to the XCDs (see the kernel)
+        const int64_t sn = p.n_tiles < 8 ? p.n_tiles : 8, supers = groups * ceil_div(p.n_tiles, sn);
+        blocks = ceil_div(supers, 8) * 8 * (8 * sn);
+    }
     if (p.max_mtiles != max_mtiles) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: max_mtiles not set in the parameter block");
     const int kblocks = p.C >> 7;
     if (p.C % 128 != 0 || kblocks < 2 || kblocks > gs128::kMaxKB)
@@ -907,7 +952,7 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
     if (terms != 0 && (p.xs_stride % 4 != 0 || ((uintptr_t)p.xs % 4) != 0)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: scale rows must be 4-byte aligned");
     if (terms == 0 && (!p.x_scale_f32 || (mode == MODE_GATE_UP && (!p.out_scale_f32 || !p.row_amax || !p.arrivals))))
         SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: int8 needs the per-row scale tables and the row-maximum exchange buffers");
-    if (mode != MODE_GATE_UP && mode != MODE_DOWN) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: mode %d", mode);
+    if (mode != MODE_GATE_UP && mode != MODE_DOWN && !(mode == MODE_PLAIN && terms != 1)) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: mode %d", mode);
     const int nmod = terms == 2 ? (kblocks - 2) % 3 : kblocks % 2;   // see run_tile: the rotation of the fragment sets
     if (terms < 0 || terms > 2) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: terms %d", terms);
 #define SGLK_LAUNCH_S128(M_, N_, A_)                                                                                      \
@@ -958,10 +1003,22 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, h
         if (nmod == 0) SGLK_LAUNCH_S128_B(MODE_GATE_UP, 0);
         else if (nmod == 1) SGLK_LAUNCH_S128_B(MODE_GATE_UP, 1);
         else SGLK_LAUNCH_S128_B(MODE_GATE_UP, 2);
-    } else {
+    } else if (mode == MODE_DOWN) {
         if (nmod == 0) SGLK_LAUNCH_S128_B(MODE_DOWN, 0);
         else if (nmod == 1) SGLK_LAUNCH_S128_B(MODE_DOWN, 1);
         else SGLK_LAUNCH_S128_B(MODE_DOWN, 2);
+    } else {   // dense rows (one "expert"): two-term fp8 or int8
+#define SGLK_LAUNCH_S128_P(N_)                                                                                                         \
+    do {                                                                                                                                \
+        if (terms == 2)                                                                                                                 \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<MODE_PLAIN, N_, 0, 2, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p); \
+        else                                                                                                                            \
+            hipLaunchKernelGGL((gs128::moe_gemm_fp8w_s128_kernel<MODE_PLAIN, (N_) & 1, 0, 1, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p); \
+    } while (0)
+        if (nmod == 0) SGLK_LAUNCH_S128_P(0);
+        else if (nmod == 1) SGLK_LAUNCH_S128_P(1);
+        else SGLK_LAUNCH_S128_P(2);
+#undef SGLK_LAUNCH_S128_P
     }
 #undef SGLK_LAUNCH_S128_B
 #undef SGLK_LAUNCH_S128

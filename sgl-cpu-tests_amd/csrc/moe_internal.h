@@ -84,6 +84,8 @@ struct A8GemmParams {
     // s128 kernel, int8 W8A8 (terms = 0): x / ic1 rows are int8 in natural k order, w = pack.hip's int8 tiles, w_scale = per weight
     // row [E][scale_rows]; one f32 factor per x row instead of xs; GATE_UP writes int8 ic1 + out_scale_f32[position] and needs
     // row_amax [M * topk] (zeroed) and arrivals [max_mtiles] (zeroed) for the per-token maximum across the m-tile's workgroups
+    const float* bias;            // s128 kernel, MODE_PLAIN (dense rows, no tile table: m-tile i = rows [128 i, 128 i + 128) of dense_rows): [output columns] f32 or null
+    int dense_rows;
     const float* x_scale_f32;
     float* out_scale_f32;
     unsigned* row_amax;

@@ -290,6 +290,48 @@ def test_fp8_scaled_mm(ops, case, prepack):
     torch.testing.assert_close(out32.cpu(), g["ref_out_f32"], rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("name", ["m500_n768_k1024_bias", "m333_n512_k2048_chunk"])
+def test_fp8_scaled_mm_goldens_on_the_128_token_kernel(ops, knob, name):
+    """Dense fp8 W8A16 on moe_gemm_fp8w_s128.hip (MODE_PLAIN: the bf16 activations as two exact e4m3 terms on the block-scaled fp8
+    matrix cores, 128-row tiles, two workgroups per CU; the default for launches of >= 1024 such tiles, here forced from 128 rows): the reference's
+    golden cases incl. the bias and the row-strided `narrow` view (/root/reference/test_gemm_fp8.py:32-58), and within rounding of
+    the 256-row bf16-MFMA kernel."""
+    case = next(c for c in recipes.GEMM_FP8_CASES if c[0] == name)
+    _, M, N, K, has_bias, chunk, seed = case
+    g, _ = load_golden("gemm_fp8_" + name)
+    inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, chunk, seed)
+    data = inp["data"].cuda() if not chunk else torch.empty(M, K + 10, dtype=torch.bfloat16, device="cuda").narrow(1, 0, K).copy_(inp["data"])
+    w = ops.convert_weight_packed(inp["w"].cuda())
+    bias = inp["bias"].cuda() if has_bias else None
+    knob(SGLK_DENSE_S128=1)
+    out = ops.fp8_scaled_mm_cpu(data, w, inp["scales"].cuda(), [64, 128], bias, data.dtype, True)
+    assert ref_pred(g["ref_out_bf16"], out), name
+    assert rel_rms(out, g["ref_out_f32"]) < 4e-3
+    assert torch.equal(out, ops.fp8_scaled_mm_cpu(data, w, inp["scales"].cuda(), [64, 128], bias, data.dtype, True))
+    knob(SGLK_DENSE_S128=0)
+    out256 = ops.fp8_scaled_mm_cpu(data, w, inp["scales"].cuda(), [64, 128], bias, data.dtype, True)
+    assert rel_rms(out, out256) < 3e-3
+
+
+@pytest.mark.parametrize("shape", [(1000, 5120, 2048, True), (4096, 1536, 2048, False), (777, 2048, 6144, True), (2049, 512, 256, False)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_fp8_scaled_mm_prefill_sizes_against_the_fp32_oracle(ops, knob, shape):
+    """Qwen3 projection shapes at prefill sizes on the default path (the 128-token two-term kernel) and on the 256-row kernel
+    (SGLK_DENSE_S128=0), against the fp32 oracle (oracle/gemm.py: /root/reference/test_gemm_fp8.py:32-45) with the reference
+    predicate; a ragged last row tile, the shortest reduction (two K blocks) and a bias included."""
+    M, N, K, has_bias = shape
+    inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, False, 4300 + M)
+    bias = inp["bias"] if has_bias else None
+    ref = ogemm.fp8_scaled_mm(inp["data"], inp["w"], inp["scales"], (64, 128), bias)
+    w = ops.convert_weight_packed(inp["w"].cuda())
+    b = bias.cuda() if has_bias else None
+    for kn in (1, 0):     # 1: the 128-token kernel from 128 rows on (by default it takes launches of >= 1024 of its tiles)
+        knob(SGLK_DENSE_S128=kn)
+        out = ops.fp8_scaled_mm_cpu(inp["data"].cuda(), w, inp["scales"].cuda(), [64, 128], b, torch.bfloat16, True)
+        assert ref_pred(ref, out), (shape, kn)
+        assert rel_rms(out, ref) < 4e-3, (shape, kn)
+
+
 @pytest.mark.parametrize("case", recipes.GEMM_INT8_CASES, ids=lambda c: c[0])
 def test_int8_gemm_ops(ops, case):
     name, M, N, K, has_bias, seed = case
@@ -315,7 +357,11 @@ def test_int8_gemm_ops(ops, case):
 
 
 @pytest.mark.parametrize("shape", [(192, 256, 256, False), (1000, 512, 1024, True), (300, 768, 4160, True), (2049, 1536, 2048, False),
-                                   (1, 256, 512, True), (64, 512, 1024, True), (128, 256, 4096, False), (37, 1536, 7168, True)],
+                                   (1, 256, 512, True), (64, 512, 1024, True), (128, 256, 4096, False), (37, 1536, 7168, True),
+                                   # Qwen3-30B-A3B projection shapes of BASELINE config 1 (/root/reference/test_gemm_int8.py:66-73 on
+                                   # "Qwen3 FFN shapes"): qkv [5120, 2048], o [2048, 4096], dense gate_up [12288, 2048], down [2048, 6144]
+                                   (1000, 5120, 2048, True), (1000, 2048, 4096, False), (1000, 12288, 2048, False), (1000, 2048, 6144, True),
+                                   (4096, 12288, 2048, True), (16, 5120, 2048, False)],
                          ids=lambda s: "x".join(map(str, s[:3])))
 def test_int8_mfma_gemm_is_exact(ops, shape):
     """Packed int8 GEMMs run on the int8 matrix cores -- mfma_i32_32x32x32_i8 (csrc/gemm_i8_256.hip) for M >= 192, the
@@ -330,7 +376,7 @@ def test_int8_mfma_gemm_is_exact(ops, shape):
     Bs = torch.rand(N, generator=g) * 1e-2 + 1e-4
     bias = torch.randn(N, generator=g) if has_bias else None
     Aq, As = ogemm.per_token_quant_int8(A)
-    acc = (Aq.long() @ Bq.long().t())                                   # exact
+    acc = (Aq.double() @ Bq.double().t()).long()                        # exact: |sum| <= 127 * 128 * K < 2^53
     exact = As.float().view(-1, 1) * acc.to(torch.float32) * Bs.view(1, -1)
     if bias is not None:
         exact = exact + bias.view(1, -1)

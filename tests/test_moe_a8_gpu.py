@@ -106,6 +106,37 @@ def test_fused_experts_a8_small_shapes(ops, a8, name):
     assert torch.equal(out, again), "a8 mode must be run-to-run bit identical (no float atomics)"
 
 
+# deviation of the a8 mode from the REFERENCE's own fp32 oracle on the reference's golden cases (tests/golden/moe_fp8_*.safetensors:
+# `ref_out_f32` = native_fused_moe of /root/reference/test_moe_fp8_ext.py:70-91 run in the build container), measured once on
+# the MI355X and committed here: (relative RMS, fraction of elements outside allclose(rtol = atol = 1e-2)).  The mode does NOT
+# meet the reference predicate -- these numbers are what a caller who opts in accepts.
+A8_VS_REFERENCE = {
+    "m1212_n512_k1024_e8_t2": (0.0463, 0.0449),
+    "m121_n512_k1024_e8_t2": (0.0465, 0.0459),
+    "masked_m300_n256_k512_e16_t8": (0.0459, 0.2594),
+    "qwen3dims_m96_e8_t8": (0.0458, 0.0891),
+}
+
+
+@pytest.mark.parametrize("name", sorted(A8_VS_REFERENCE))
+def test_a8_deviation_from_the_reference_oracle_is_pinned(ops, a8, name):
+    from conftest import load_golden
+    case = next(c for c in recipes.MOE_FP8_CASES if c[0] == name)
+    _, M, N, K, E, topk, bn, bk, masked, seed, _full = case
+    g, _ = load_golden("moe_fp8_" + name)
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed)
+    out = run(ops, inp, (bn, bk)).float().cpu()
+    ref = g["ref_out_f32"].float()
+    rel = float((out - ref).norm() / ref.norm())
+    outside = float((~torch.isclose(out.bfloat16().float(), ref.bfloat16().float(), rtol=1e-2, atol=1e-2)).float().mean())
+    print(f"[a8 vs reference oracle] {name}: relative RMS {rel:.4f}, fraction outside allclose(1e-2) {outside:.4f}")
+    want_rel, want_out = A8_VS_REFERENCE[name]
+    if want_rel is not None:
+        assert abs(rel - want_rel) <= 0.1 * want_rel + 1e-4, f"{name}: relative RMS {rel:.4f}, committed {want_rel}"
+        assert abs(outside - want_out) <= 0.1 * want_out + 2e-3, f"{name}: fraction outside {outside:.4f}, committed {want_out}"
+    assert rel < 0.08 and torch.isfinite(out).all()
+
+
 def test_fused_experts_a8_scale_extremes(ops, a8):
     """Block scales over 2^-12 .. 2^4 with random sign, a zero block, ragged expert loads (rows per expert far from 256)."""
     M, N, K, E, topk, bn, bk = 1531, 256, 512, 8, 4, 128, 128
