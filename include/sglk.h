@@ -143,7 +143,7 @@ enum {
 /* path_taken: tile height of the grouped GEMMs (32 / 96 / 128 / 256; 64 = generic engine) | flag bits */
 enum {
     SGLK_PATH_TILE_MASK = 0x3ff,
-    SGLK_PATH_FP8_ACT = 0x1000,       /* a8 kernels (moe_gemm_a8.hip) */
+    SGLK_PATH_FP8_ACT = 0x1000,       /* a8 mode (moe_gemm_fp8w_s128.hip, one e4m3 term) */
     SGLK_PATH_TAILS_SPLIT = 0x2000,   /* tail tiles on the mid kernel */
     SGLK_PATH_TAILS_AUX = 0x4000,     /* ... on the caller's aux stream */
     SGLK_PATH_PERSIST_G1 = 0x8000,    /* GEMM-1 launched persistent (one workgroup per CU, tile loop + tickets) */
@@ -203,7 +203,7 @@ int sglk_moe_block(const sglk_moe_block_args* args, void* stream);
 int sglk_quant_fp8_block128(const void* x, int64_t x_stride, void* q, int64_t q_stride, void* scale, int64_t scale_stride,
                             int64_t rows, int32_t cols, void* stream);
 
-/* First stage of the W8A16 path on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip), exported so that the exactness of
+/* First stage of the W8A16 path on the scaled fp8 matrix cores (moe_gemm_fp8w_s128.hip; fp8_split.h), exported so that the exactness of
  * the split can be checked on its own: x [rows][cols] bf16 -> q [rows][2*cols] bytes + scale [rows][scale_stride] E8M0 bytes.
  * Per 128-wide block: s = 2^(byte-127), the smallest power of two with amax / s <= 448 (byte >= 5); per element
  * hi = e4m3(x / s), lo = e4m3((x - hi * s) / (s / 16)): x == hi * s + lo * s / 16 EXACTLY for every element within 2^13 of

@@ -58,9 +58,7 @@ void read_env() {
     k.no_pack_on_the_fly = env_set("SGLK_NO_PACK_ON_THE_FLY");
     k.inline_align_max = env_int("SGLK_INLINE_ALIGN_MAX", 16);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
-    k.split = env_int("SGLK_SPLIT", -1);
     k.s128 = env_int("SGLK_S128", -1);
-    k.a8_s128 = env_int("SGLK_A8_S128", -1);
     k.i8_s128 = env_int("SGLK_I8_S128", -1);
     k.dense_s128 = env_int("SGLK_DENSE_S128", -1);
     k.ar_wait_ms = env_int("SGLK_AR_WAIT_MS", 0);

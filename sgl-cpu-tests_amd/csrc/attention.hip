@@ -601,7 +601,7 @@ struct CorePP {
         for (int i = 0; i < KS * NKT; ++i) {
             const int ks = i / NKT, kt = i % NKT;
             const int row = kt * 16 + r;
-#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 4)       // timing ablation 4: no operand reads
+#if (SGLK_PP_ABL & 4)       // timing ablation 4: no operand reads
             kf[i] = qf[0][ks];
             (void)row;
 #else
@@ -612,7 +612,7 @@ struct CorePP {
         for (int i = 0; i < KS * NKT; ++i) {
             const int ks = i / NKT, kt = i % NKT;
 #pragma unroll
-#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 8)       // timing ablation 8: no MFMAs (the reads stay)
+#if (SGLK_PP_ABL & 8)       // timing ablation 8: no MFMAs (the reads stay)
             asm volatile("" ::"v"(kf[i]));
             (void)ks; (void)kt;
 #else
@@ -631,7 +631,7 @@ struct CorePP {
     }
     // online softmax of the tile in `s` -> `pf` (same arithmetic as Core::tile)
     SGLK_DEV void softmax(int key_base, const int (&limit)[QT], float scale_log2e, float logit_cap, int lane) {
-#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 1)     // timing ablation: no softmax arithmetic (wrong results)
+#if (SGLK_PP_ABL & 1)     // timing ablation: no softmax arithmetic (wrong results)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -733,7 +733,7 @@ struct CorePP {
             const int ch = col >> 3, sub = (col & 7) * 2;
             const unsigned char* a0 = vlds + row0 * (DV * 2) + ((ch ^ vswz(row0)) << 4) + sub;
             const unsigned char* a1 = vlds + row1 * (DV * 2) + ((ch ^ vswz(row1)) << 4) + sub;
-#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 4)
+#if (SGLK_PP_ABL & 4)
             lo[i] = __builtin_bit_cast(s16x4, (uint2){(unsigned)i, 0u});
             hi[i] = lo[i];
             (void)a0; (void)a1;
@@ -749,7 +749,7 @@ struct CorePP {
             vv[0] = lo[i][0]; vv[1] = lo[i][1]; vv[2] = lo[i][2]; vv[3] = lo[i][3];
             vv[4] = hi[i][0]; vv[5] = hi[i][1]; vv[6] = hi[i][2]; vv[7] = hi[i][3];
             const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-#if defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 8)
+#if (SGLK_PP_ABL & 8)
             asm volatile("" ::"v"(vf));
             (void)t; (void)ss;
 #else
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(512, 2) void extend_pp_kernel(const ExtendParams p)
         slot_barrier_v();                       // the halves issued one slot ago have landed
         // ---- M_t ----
         __builtin_amdgcn_s_setprio(SGLK_PP_PRIO);    // the matrix-slot wave wins the SIMD's issue arbitration (+2 %)
-#if !(defined(SGLK_PP_ABLATE) && (SGLK_PP_ABLATE & 2))   // timing ablation 2: no matrix slot (wrong results)
+#if !(SGLK_PP_ABL & 2)   // timing ablation 2: no matrix slot (wrong results)
         if (t < nt_w) core.pv(vring + (t % 3) * VB, lane);
         if (t + 1 < nt_w) core.qk(kring + ((t + 1) % 3) * KB, lane);
 #endif

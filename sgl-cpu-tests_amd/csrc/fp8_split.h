@@ -1,5 +1,16 @@
-// Two-term e4m3 split of bf16 activations (see moe_gemm_fp8w_split.hip for why it is exact): shared by the W8A16 split kernel
-// and the native MX-fp4 GEMM (gemm_mxfp4.hip).
+// Two-term e4m3 split of bf16 activations: shared by the W8A16 kernels on the block-scaled fp8 matrix cores
+// (moe_gemm_fp8w_s128.hip) and the native MX-fp4 GEMM (gemm_mxfp4.hip).
+//
+// Why: v_mfma_scale_f32_32x32x64_f8f6f4 multiplies fp8 x fp8 at twice the bf16 rate and takes fp8 weights AS THEY ARE (no
+// fp8 -> bf16 conversion in the loop).  A bf16 activation has 8 significant bits, an e4m3 value 4: x = hi + lo with
+//     hi = e4m3(x / s),   lo = e4m3((x - hi * s) / (s / 16)),   s = 2^sb the block's power-of-two scale (amax / s <= 448)
+// is EXACT for every element within 2^13 of its 128-block's largest magnitude (hi is then a normal e4m3 number; the residual of
+// the first rounding has at most four significant bits and sits at most 2^-4 below the element); smaller elements lose bits
+// below 2^-21 * amax(block) -- four orders of magnitude under the bf16 rounding of the result.  Two scaled MFMAs (hi, lo) per
+// 64-wide k group cost the matrix pipe exactly what the four bf16 MFMAs of the same k range cost; products stay exact,
+// accumulation fp32, the weights' block scales exact (power of two in the instruction, mantissa by the accumulator-unit trick).
+// A split row stores, for every 64-wide k group, [hi 64 B | lo 64 B] in the k order of the packed weight tile = 128 contiguous
+// bytes per token and stage (one cache line); one E8M0 byte per token and 128-wide block.
 #pragma once
 #include "sglk_common.h"
 
@@ -17,7 +28,7 @@ SGLK_DEV int e8m0_for_amax(float amax) {
 SGLK_DEV float inv_scale_of(int sb) { return __uint_as_float((unsigned)(254 - sb) << 23); }   // 2^(127 - sb), exact
 
 
-SGLK_DEV int sp_e8m0_for_amax(float amax) {   // as e8m0_for_amax of moe_gemm_a8.hip, floor 5 so that the lo scale (sb - 4) >= 1
+SGLK_DEV int sp_e8m0_for_amax(float amax) {   // as e8m0_for_amax above, floor 5 so that the lo scale (sb - 4) >= 1
     const unsigned u = __float_as_uint(amax);
     int sb = (int)(u >> 23) - 8 + ((u & 0x7fffffu) > 0x600000u ? 1 : 0);
     sb = sb < 5 ? 5 : (sb > 253 ? 253 : sb);

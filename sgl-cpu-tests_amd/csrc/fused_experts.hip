@@ -13,9 +13,7 @@ using namespace sglk;
 
 namespace {
 
-constexpr bool kSplitDefault = false;   // which 256-row W8A16 kernel runs when SGLK_SPLIT is unset
 constexpr bool kS128Default = true;
-constexpr bool kA8S128Default = true;   // the opt-in a8 mode on the 128-token kernel when SGLK_A8_S128 is unset
 constexpr bool kI8S128Default = true;   // large-M int8 W8A8 on the 128-token kernel (exact int32 sums, ic1 quantised in GEMM-1's epilogue) when SGLK_I8_S128 is unset
     // large-M W8A16 on the 128-token two-workgroups-per-CU split kernel when SGLK_S128 is unset
 
@@ -65,7 +63,7 @@ int pick_tile_m(int M, int N, int K, int E, int topk, int block_n, int64_t hidde
     // With the 128-token two-workgroups-per-CU kernel behind the "256" answer (moe_gemm_fp8w_s128.hip: one tile per expert at 128
     // rows, token tiles without rows skipped) the crossover sits at ~64 rows per expert: M = 1024 / 1536 / 2048 at Qwen3 dims
     // 419 -> 432 / 464 -> 559 / 519 -> 591 TFLOP/s (profiles/r03_ab_mid_vs_s128.txt)
-    const bool s128_next = ok256 && moe_gemm_fp8w_s128_ok(N, K, block_n) && (kn.s128 >= 0 ? kn.s128 == 1 : (kS128Default && kn.split < 0)) &&
+    const bool s128_next = ok256 && moe_gemm_fp8w_s128_ok(N, K, block_n) && (kn.s128 >= 0 ? kn.s128 == 1 : kS128Default) &&
                            (int64_t)M * K * 2 < (1ll << 32) && S * (int64_t)N * 2 < (1ll << 32);
     const int64_t lo = kn.mid_lo, hi = kn.mid_hi > 0 ? kn.mid_hi : (s128_next ? 64 : ((N <= 512 && K >= 4096) ? 72 : 160));
     if (ok_stream && S < lo * E) return kStreamTileM;
@@ -288,13 +286,12 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     // the 256-row regime on 128-token tiles, four waves, two workgroups per CU (moe_gemm_fp8w_s128.hip): the two-term split
     // whose prologue / epilogue hide behind the co-resident workgroup's main loop
     // (the default only when no test knob pins a tiling or one of the 256-row kernels; SGLK_S128=1 / 0 forces / forbids it)
-    const bool s128_on = knobs().s128 >= 0 ? knobs().s128 == 1 : (kS128Default && knobs().moe_tile_m == 0 && knobs().split < 0);
+    const bool s128_on = knobs().s128 >= 0 ? knobs().s128 == 1 : (kS128Default && knobs().moe_tile_m == 0);
     const bool s128 = tuned && !a8 && tile_m == 256 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (int64_t)M * K * 2 < (1ll << 32) &&
                       (int64_t)M * topk * N * 2 < (1ll << 32) && s128_on;
     if (s128) tile_m = 128;
-    const bool a8s = a8 && moe_gemm_fp8w_s128_ok(N, K, a->block_n) && (knobs().a8_s128 >= 0 ? knobs().a8_s128 == 1 : kA8S128Default);
+    const bool a8s = a8;   // (the a8 request was checked against moe_gemm_fp8w_s128_ok's shape rules above)
     if (a8s) tile_m = 128;
-    SGLK_REQUIRE(!a8 || a8s || (K <= 4096 && N <= 4096), SGLK_ERR_SHAPE, "fused_experts: the 256-row a8 kernels (SGLK_A8_S128=0) take K, N <= 4096");
     const bool i8s = tuned_i8 && moe_gemm_fp8w_s128_ok(N, K, 32) && (knobs().i8_s128 >= 0 ? knobs().i8_s128 == 1 : kI8S128Default);
     if (i8s) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
@@ -335,8 +332,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     const int inline_max = knobs().inline_align_max < kInlineAlignSlots ? knobs().inline_align_max : kInlineAlignSlots;
     const bool inline_align = tuned && !a8 && tile_m == kStreamTileM && !route && !split_tails && (int64_t)M * topk <= inline_max;
     // the two-term split of `hidden` (W8A16 on the scaled fp8 MFMA) rides in moe_align's second launch as extra workgroups
-    const bool want_split = s128 || (tuned && !a8 && tile_m == 256 && K <= 4096 && N <= 4096 && (int64_t)M * K * 2 < (1ll << 32) &&
-                                     (int64_t)M * topk * N * 2 < (1ll << 32) && (knobs().split >= 0 ? knobs().split == 1 : kSplitDefault));
+    const bool want_split = s128;
     SplitJob sjob{};
     bool split_done = false;
     if (want_split) {
@@ -384,8 +380,8 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     mark(1);
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
 
-    // 256-row regime: the two-term e4m3 split on the scaled fp8 matrix cores (moe_gemm_fp8w_split.hip) instead of the
-    // bf16-MFMA kernel -- the same W8A16 contract (SGLK_SPLIT=0 / 1 overrides)
+    // large batches: the two-term e4m3 split on the scaled fp8 matrix cores, 128-token tiles (moe_gemm_fp8w_s128.hip) -- the same
+    // W8A16 contract as the bf16-MFMA kernels below (SGLK_S128=0 / 1 overrides)
     const bool split = want_split;
     if (split) {
         uint8_t* xq = ws + w.xq;
@@ -397,61 +393,6 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
             rc = launch_split_fp8_block128((const uint16_t*)a->hidden, a->hidden_stride, xq, 2 * (int64_t)K, xs, xs_stride, M, K, s);
             if (rc != SGLK_OK) return rc;
             mark(1);   // the split pass counts towards the align stage
-        }
-        hipEvent_t ev_join = nullptr;
-        if (split_tails) {   // the short tail tiles run on the weight-streaming bf16-MFMA kernel (their own rows of ic1 / ic2)
-            const int tails_max = E < max_tiles ? E : max_tiles;
-            MoeGemmParams t1{};
-            t1.x = (const uint16_t*)a->hidden;
-            t1.x_stride = a->hidden_stride;
-            t1.x_bytes = (int64_t)M * a->hidden_stride * 2;
-            t1.sorted_slot = sorted_slot;
-            t1.topk = topk;
-            t1.w = (const uint8_t*)a->w1;
-            t1.w_expert_stride = (int64_t)2 * N * K;
-            t1.w_scale = a->w1_scale;
-            t1.scale_rows = (int)ceil_div(2 * N, a->block_n);
-            t1.scale_cols = K / 128;
-            t1.block_n = a->block_n;
-            t1.C = K;
-            t1.n_half = N;
-            t1.tile_info = (const int4*)tile_info_b;
-            t1.num_tiles = num_tiles_b;
-            t1.n_tiles = N / 128;
-            t1.out = ic1;
-            t1.out_stride = N;
-            MoeGemmParams t2{};
-            t2.x = ic1;
-            t2.x_stride = N;
-            t2.x_bytes = (int64_t)M * topk * N * 2;
-            t2.sorted_slot = sorted_slot;
-            t2.topk = topk;
-            t2.w = (const uint8_t*)a->w2;
-            t2.w_expert_stride = (int64_t)K * N;
-            t2.w_scale = a->w2_scale;
-            t2.scale_rows = (int)ceil_div(K, a->block_n);
-            t2.scale_cols = N / 128;
-            t2.block_n = a->block_n;
-            t2.C = N;
-            t2.tile_info = (const int4*)tile_info_b;
-            t2.num_tiles = num_tiles_b;
-            t2.n_tiles = K / 128;
-            t2.out = ic2;
-            t2.out_stride = K;
-            t2.topk_weights = a->topk_weights;
-            hipStream_t ts = s;
-            if (side) {
-                hipEvent_t ev_fork = (hipEvent_t)a->aux_events[0];
-                ev_join = (hipEvent_t)a->aux_events[1];
-                if (hipEventRecord(ev_fork, s) != hipSuccess || hipStreamWaitEvent((hipStream_t)a->aux_stream, ev_fork, 0) != hipSuccess)
-                    SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream fork failed");
-                ts = (hipStream_t)a->aux_stream;
-            }
-            rc = launch_moe_gemm_fp8w_mid(MODE_GATE_UP, t1, tails_max, ts);
-            if (rc != SGLK_OK) return rc;
-            rc = launch_moe_gemm_fp8w_mid(MODE_DOWN, t2, tails_max, ts);
-            if (rc != SGLK_OK) return rc;
-            if (side && hipEventRecord(ev_join, ts) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream record failed");
         }
         A8GemmParams q1{};
         q1.x = xq;
@@ -480,7 +421,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
-        rc = s128 ? launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s) : launch_moe_gemm_fp8w_split(MODE_GATE_UP, q1, max_tiles, s);
+        rc = launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
         A8GemmParams q2{};
@@ -508,12 +449,11 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
 #ifdef SGLK_DEV_ABLATE
         if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
 #endif
-        rc = s128 ? launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s) : launch_moe_gemm_fp8w_split(MODE_DOWN, q2, max_tiles, s);
+        rc = launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
-        if (ev_join && hipStreamWaitEvent(s, ev_join, 0) != hipSuccess) SGLK_FAIL(SGLK_ERR_LAUNCH, "fused_experts: aux-stream join failed");
         mark(3);
     } else if (a8) {
-        // quantise hidden (one pass), GEMM-1 + SiLU*mul + ic1 quantisation, GEMM-2 + routing weight (moe_gemm_a8.hip)
+        // quantise hidden (one pass), GEMM-1 + SiLU*mul + ic1 quantisation, GEMM-2 + routing weight (moe_gemm_fp8w_s128.hip, one e4m3 term)
         uint8_t* xq = ws + w.xq;
         uint8_t* xs = ws + w.xs;
         uint8_t* ic1q = ws + w.ic1q;
@@ -551,7 +491,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         if (knobs().dbg_ptr) q1.dbg = (unsigned long long*)knobs().dbg_ptr;
 #endif
         q1.max_mtiles = max_tiles;
-        rc = a8s ? launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s, 1) : launch_moe_gemm_a8(MODE_GATE_UP, q1, max_tiles, s);
+        rc = launch_moe_gemm_fp8w_s128(MODE_GATE_UP, q1, max_tiles, s, 1);
         if (rc != SGLK_OK) return rc;
         mark(2);
         A8GemmParams q2{};
@@ -579,7 +519,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         if (q1.dbg) q2.dbg = q1.dbg + 32 * 16384;
 #endif
         q2.max_mtiles = max_tiles;
-        rc = a8s ? launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s, 1) : launch_moe_gemm_a8(MODE_DOWN, q2, max_tiles, s);
+        rc = launch_moe_gemm_fp8w_s128(MODE_DOWN, q2, max_tiles, s, 1);
         if (rc != SGLK_OK) return rc;
         mark(3);
     } else if (tuned) {

@@ -36,9 +36,7 @@ struct Knobs {
     int attn_order = -1;         // SGLK_ATTN_ORDER: A/B override of the extend-attention dispatch order
     int inline_align_max = 16;   // SGLK_INLINE_ALIGN_MAX: fused_experts with at most this many slots (<= 32) sorts the ids in the GEMM kernels, no moe_align launch; 0 = never (A/B)
     bool no_block_fold = false;  // SGLK_NO_BLOCK_FOLD: sglk_moe_block runs router / align / combine / shared expert unfused (A/B)
-    int split = -1;              // SGLK_SPLIT: 0 = bf16-MFMA 256-row kernel, 1 = two-term e4m3 split on the scaled fp8 MFMA; unset = default
     int s128 = -1;               // SGLK_S128: 1 / 0 = the split on 128-token tiles with two workgroups per CU (moe_gemm_fp8w_s128.hip) / never; unset = default
-    int a8_s128 = -1;            // SGLK_A8_S128: 1 / 0 = the a8 mode on the 128-token kernel (moe_gemm_fp8w_s128.hip, one term) / on moe_gemm_a8.hip
     int ar_wait_ms = 0;          // SGLK_AR_WAIT_MS: how long the direct all-reduce waits for a peer before it gives up (default 30000)
     int dense_s128 = -1;         // SGLK_DENSE_S128: 0 = dense fp8 / int8 GEMMs never on the 128-token kernel; 1 = from 128 rows; unset = from 1024 of its tiles
     int i8_s128 = -1;            // SGLK_I8_S128: 1 / 0 = large-M int8 W8A8 fused_experts on the 128-token kernel (terms = 0) / on gemm_i8_256.hip

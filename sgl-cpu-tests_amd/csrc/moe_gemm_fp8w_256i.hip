@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // stage are issued ONE PER MFMA GROUP, never as a burst: a buffer_load...lds costs the issuing wave 60-180 cycles,
     // which hides behind the MFMAs already queued on the matrix pipe but stalls the wave when six come back to back.
     auto issue_piece = [&](int kt, int buf, int i) __attribute__((always_inline)) {
-        if ((RESCALE & 64) && kt > 2) return;   // bit 6: timing ablation, no LDS-DMA in the steady state
+        if (SGLK_ABL(RESCALE, 64) && kt > 2) return;   // bit 6: timing ablation, no LDS-DMA in the steady state
         unsigned char* sx = smem + buf * kStage;
         if (i < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lptr_t)(sx + (wave * 4 + i) * 1024), 16, xsrc[i], kt * 128, 0, 0);
@@ -357,13 +357,13 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     // tiles (32 tokens) that hold no row at all are skipped: no fragment read, no MFMA, no rescale (nta = tiles with rows)
     auto ld_x = [&](int par, int tt, int fbuf, int ks, bool chk) __attribute__((always_inline)) {
         if (chk && tt >= nta) return;
-        if ((RESCALE & 16) && (ks | tt)) return;   // timing ablation: one X read per stage
+        if (SGLK_ABL(RESCALE, 16) && (ks | tt)) return;   // timing ablation: one X read per stage
         xf[par][tt] = *reinterpret_cast<const u32x4*>(smem + fbuf * kStage + xoff(tt, ks));
     };
     // words 2*half, 2*half+1 of the converted row tile rt (octet low / high dword of the raw pair)
     auto cvt2 = [&](int par, int rt, int half, float sc2) __attribute__((always_inline)) {
         const unsigned src = half ? wraw[rt][1] : wraw[rt][0];
-        if (RESCALE & 8) { wfw[par][rt][2 * half] = src; wfw[par][rt][2 * half + 1] = src; return; }   // timing ablation: no conversion
+        if (SGLK_ABL(RESCALE, 8)) { wfw[par][rt][2 * half] = src; wfw[par][rt][2 * half + 1] = src; return; }   // timing ablation: no conversion
         wfw[par][rt][2 * half] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, false));
         wfw[par][rt][2 * half + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(src, sc2, true));
     };
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
                                                               __builtin_bit_cast(bf16x8, xf[par][tt]), acc[rt][tt], 0, 0, 0);
     };
     auto rescale = [&](int a, bool chk) __attribute__((always_inline)) {   // accumulator of MFMA slot a into units of the next K block's mantissa
-        if (RESCALE & 4) return;   // timing ablation: no rescale
+        if (SGLK_ABL(RESCALE, 4)) return;   // timing ablation: no rescale
         const int rt = slot_rt(a), tt = slot_tt(a);
         if (chk && tt >= nta) return;
         // one plain v_mul_f32 per register: beside MFMAs a packed v_pk_mul_f32 costs the wave ~3x the issue time of the
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_256i_kernel(const MoeGem
     auto sync_point = [&](bool wait6) __attribute__((always_inline)) {
         if (wait6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (RESCALE & 1024) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // timing ablation: NO barrier (racy)
+        if (SGLK_ABL(RESCALE, 1024)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // timing ablation: NO barrier (racy)
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 

@@ -1,12 +1,12 @@
 // Large-M grouped W8A16 GEMM of fused_experts, two-term e4m3 split on the block-scaled fp8 matrix cores, 128-token tiles,
-// TWO workgroups per CU.  Same operator contract, oracle and data formats as moe_gemm_fp8w_split.hip
+// TWO workgroups per CU.  Operator contract, oracle and data formats: fp8_split.h
 // (/root/reference/test_moe_fp8_ext.py:22-25,70-91; /root/reference/bench_moe.py:113-130): x = hi + lo exactly, both terms e4m3
 // under one power-of-two scale per (row, 128-wide block); rows are [hi 64 | lo 64] per 64-wide k group in the packed weight
 // tile's k order.
 //
-// Why another tiling.  The 256 x 256 / 8-wave split kernel runs its main loop at 91 % of the matrix pipe but a tile also
-// spends 3.6 us in its prologue (tile table -> row ids -> first operands: dependent round trips) and 7.2 us in its epilogue
-// (SiLU, the split of ic1, stores), with the pipe idle: one workgroup owns the whole CU.  Here a workgroup is FOUR waves (one
+// Why this tiling.  A 256 x 256 / 8-wave form of the same split (round 2; deleted in round 3) ran its main loop at 91 % of the
+// matrix pipe but a tile also spent 3.6 us in its prologue (tile table -> row ids -> first operands: dependent round trips) and
+// 7.2 us in its epilogue (SiLU, the split of ic1, stores), with the pipe idle: one workgroup owned the whole CU.  Here a workgroup is FOUR waves (one
 // per SIMD) with a tile of 128 tokens x 256 weight rows, and a CU holds TWO of them (2 x 71 KiB of LDS, 2 x 256 registers
 // per SIMD lane): while one is in its prologue or epilogue the other has the matrix pipe to itself, and a 64-cycle
 // v_mfma_scale_f32_32x32x64_f8f6f4 leaves one wave alone enough issue slots to keep the pipe full.
@@ -82,7 +82,7 @@ struct TileId {
 // skips the fragment reads, MFMAs and rescales of the token tiles without rows.  The whole tile is compiled per count (a
 // run-time test in front of every MFMA, or a switch around the main loop alone, cost the register allocator 30-100 spills).
 // TERMS = e4m3 terms per activation: 2 = the exact two-term split of the bf16 value (W8A16, the reference's numerics); 1 = the
-// opt-in a8 mode (activations QUANTISED to e4m3 per token x 128 block: moe_gemm_a8.hip's formats and oracle, half the MFMAs,
+// opt-in a8 mode (activations QUANTISED to e4m3 per token x 128 block: fp8_split.h: quant_row_block128, oracle/moe_a8.py; half the MFMAs,
 // X bytes and LDS reads per stage).
 // I8 = the int8 W8A8 operator (/root/reference/test_moe_int8.py:59-94, bench_moe.py:89-106) on the same pipeline: one int8 term
 // per activation (TERMS = 1 data movement), weights in pack.hip's int8 tiles (natural k order), two mfma_i32_32x32x32_i8 per
@@ -346,7 +346,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     // accumulator tile (rt, tt) into units of the next K block's mantissa, four registers (chunk c) at a time: a wave that has
     // its SIMD to itself is issue-bound, so the 128 multiplies of a K-block boundary are spread four per tile and MFMA slot
     auto rescale4 = [&](int rt, int tt, int c) __attribute__((always_inline)) {
-        if ((ABL & 1) || I8) return;
+        if (SGLK_ABL(ABL, 1) || I8) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm("v_mul_f32 %0, %1, %0" : "+v"(acc[rt][tt][c * 4 + i]) : "s"(ratio[rt]));
     };
@@ -416,10 +416,10 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
                 if (q == 0 && tt + 1 < NTA) ld_bh(tt + 1, buf);
             }
             if (q == kSP / 4 - 1 && bound && tt < NTA && !I8) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
-            if (s2 == 0 && lda && !(ABL & 4)) ld_a(as2, 0, t + 2);
-            if (s2 == kSP / 4 && lda && !(ABL & 4)) ld_a(as2, 1, t + 2);
-            if (TERMS == 2 && s2 == 2 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 2);
-            if (TERMS == 2 && s2 == 6 && carry && !(ABL & 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 3);
+            if (s2 == 0 && lda && !SGLK_ABL(ABL, 4)) ld_a(as2, 0, t + 2);
+            if (s2 == kSP / 4 && lda && !SGLK_ABL(ABL, 4)) ld_a(as2, 1, t + 2);
+            if (TERMS == 2 && s2 == 2 && carry && !SGLK_ABL(ABL, 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 2);
+            if (TERMS == 2 && s2 == 6 && carry && !SGLK_ABL(ABL, 2)) issue_x(t + 3, buf == 0 ? kRing - 1 : buf - 1, 3);
             if (bound && !I8) rescale_slot(s2);
             if (first && !I8) rescale_slot(kSP + s2);
             if (s2 == kSP - 3 + (TERMS == 1) && wait >= 0) {   // behind slot 13 (two terms) / 6: every fragment of this stage has been read
@@ -429,9 +429,9 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
                 __builtin_amdgcn_s_barrier();
                 ld_bh(0, nbuf);
             }
-            if (s2 == kSP - 2 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 0);
+            if (s2 == kSP - 2 && dmax && !SGLK_ABL(ABL, 2)) issue_x(t + 4, buf, 0);
             if (TERMS == 2 && s2 == 15 && wait >= 0) ld_bl(0, nbuf);
-            if (s2 == kSP - 1 && dmax && !(ABL & 2)) issue_x(t + 4, buf, 1);
+            if (s2 == kSP - 1 && dmax && !SGLK_ABL(ABL, 2)) issue_x(t + 4, buf, 1);
             SGLK_FENCE();
         }
         buf = nbuf;
@@ -489,25 +489,25 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
             const int tt = s2 >> 1, q = s2 & 1;
             if (tt < NTA) mma(as, s2);
             SGLK_FENCE();
-            if (q == 0 && tt + 1 < NTA && !((ABL & 32) && d >= kFar)) ld_bh(tt + 1, buf);   // the other window has been free since the previous tile's second MFMA
+            if (q == 0 && tt + 1 < NTA && !(SGLK_ABL(ABL, 32) && d >= kFar)) ld_bh(tt + 1, buf);   // the other window has been free since the previous tile's second MFMA
             if (q == 1 && bound && tt < NTA && !I8) xsv[tt] = xs_tab[((t >> 1) + 1) * kBM + tt * 32 + r32];
             // one vector-memory instruction per MFMA slot (the four waves run in step, so a burst of one wave is a burst of four
             // in front of the CU's one 64-byte-per-clock address path)
-            if (s2 < 4 && lda && !((ABL & 4) && d >= kFar)) ld_a_half(as3, s2 >> 1, t + 3, s2 & 1);
+            if (s2 < 4 && lda && !(SGLK_ABL(ABL, 4) && d >= kFar)) ld_a_half(as3, s2 >> 1, t + 3, s2 & 1);
             if (bound && !I8) rescale_slot(s2);
             if (first && !I8) rescale_slot(8 + s2);
             if (s2 == 6 && d >= 1) {   // every fragment of this stage has been read
-                if ((ABL & 16) && d >= kFar) __builtin_amdgcn_s_waitcnt(wc(63, 0));   // developer builds: ABL = timing ablations, wrong results
+                if (SGLK_ABL(ABL, 16) && d >= kFar) __builtin_amdgcn_s_waitcnt(wc(63, 0));   // developer builds: ABL = timing ablations, wrong results
                 else if (n_wait == 12) __builtin_amdgcn_s_waitcnt(wc(12, 0));        // (the builtin wants a literal)
                 else if (n_wait == 10) __builtin_amdgcn_s_waitcnt(wc(10, 0));
                 else if (n_wait == 8) __builtin_amdgcn_s_waitcnt(wc(8, 0));
                 else if (n_wait == 4) __builtin_amdgcn_s_waitcnt(wc(4, 0));
                 else __builtin_amdgcn_s_waitcnt(wc(0, 0));
-                if (!((ABL & 8) && d >= kFar)) __builtin_amdgcn_s_barrier();
-                if (!((ABL & 32) && d >= kFar)) ld_bh(0, nbuf);
+                if (!(SGLK_ABL(ABL, 8) && d >= kFar)) __builtin_amdgcn_s_barrier();
+                if (!(SGLK_ABL(ABL, 32) && d >= kFar)) ld_bh(0, nbuf);
             }
-            if (s2 == 6 && dmax && !((ABL & 2) && d >= kFar)) issue_x(t + 8, buf, 0);
-            if (s2 == 7 && dmax && !((ABL & 2) && d >= kFar)) issue_x(t + 8, buf, 1);
+            if (s2 == 6 && dmax && !(SGLK_ABL(ABL, 2) && d >= kFar)) issue_x(t + 8, buf, 0);
+            if (s2 == 7 && dmax && !(SGLK_ABL(ABL, 2) && d >= kFar)) issue_x(t + 8, buf, 1);
             SGLK_FENCE();
         }
         buf = nbuf;
@@ -708,7 +708,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
         }
     } else if constexpr (MODE == MODE_GATE_UP && TERMS == 1) {
         // a8: ic1 = silu(gate) * up for this workgroup's 128 columns = ONE K block of GEMM-2, quantised like `hidden`: per-token
-        // amax over the four waves, power-of-two scale, e4m3, stored in the packed-tile k order (moe_gemm_a8.hip's formats)
+        // amax over the four waves, power-of-two scale, e4m3, stored in the packed-tile k order (quant_row_block128's format)
         float v[4][16];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {

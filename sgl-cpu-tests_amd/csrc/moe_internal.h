@@ -57,7 +57,7 @@ int launch_moe_gemm_fp8w(int mode, const MoeGemmParams& p, int max_mtiles, hipSt
 int launch_moe_gemm_fp8w_256i(int mode, const MoeGemmParams& p, int max_mtiles, hipStream_t stream);
 bool moe_gemm_fp8w_256i_is_persistent(int C, int64_t tiles);   // what that launch does for `tiles` workgroup tiles
 
-// ---- opt-in a8 mode: fp8 activations x fp8 weights on the block-scaled fp8 matrix cores (moe_gemm_a8.hip) -----------------
+// ---- the fp8 / int8 matrix-core kernels on 128-token tiles (moe_gemm_fp8w_s128.hip): W8A16 two-term split, opt-in a8 mode, int8 ----
 struct A8GemmParams {
     const uint8_t* x;             // quantised activations: e4m3, packed-tile k order inside every 64 group
     int64_t x_stride;             // bytes per row
@@ -72,7 +72,7 @@ struct A8GemmParams {
     int scale_rows, scale_cols, block_n;
     int C;                        // reduction length
     int n_half;                   // GATE_UP: N
-    const int4* tile_info;        // tile_m = 256
+    const int4* tile_info;        // tile_m = 128
     const int* num_tiles;
     int n_tiles;                  // GATE_UP: N / 128; DOWN: K / 256
     void* out;                    // GATE_UP: ic1 e4m3 [position][N] (same k order); DOWN: ic2 bf16 [slot][K]
@@ -93,13 +93,11 @@ struct A8GemmParams {
     float quant_floor;
     unsigned long long* dbg;      // developer builds only (SGLK_DEV_ABLATE): per-workgroup 100 MHz time stamps
 };
-int launch_moe_gemm_a8(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
-// W8A16 with EXACT bf16 activations as two e4m3 terms (hi + lo) on the block-scaled fp8 matrix cores (moe_gemm_fp8w_split.hip):
-// x / ic1 rows are [hi 64 | lo 64] per 64-wide k group (x_stride / out_stride = 2 * C bytes), one E8M0 byte per 128 block
-int launch_moe_gemm_fp8w_split(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream);
-// the same contract on 128-token tiles, four waves, two workgroups per CU, weights streamed global -> VGPR
+// W8A16 with EXACT bf16 activations as two e4m3 terms (hi + lo) on the block-scaled fp8 matrix cores (fp8_split.h):
+// x / ic1 rows are [hi 64 | lo 64] per 64-wide k group (x_stride / out_stride = 2 * C bytes), one E8M0 byte per 128 block;
+// 128-token tiles, four waves, two workgroups per CU, weights streamed global -> VGPR
 // (moe_gemm_fp8w_s128.hip); tile table built with tile_m = 128; GATE_UP n_tiles = N / 128, DOWN n_tiles = K / 256
-// terms = 2: x / ic1 rows are the two-term split (above); terms = 1: the a8 mode's quantised rows (moe_gemm_a8.hip's formats);
+// terms = 2: x / ic1 rows are the two-term split (above); terms = 1: the a8 mode's quantised rows (fp8_split.h: quant_row_block128);
 // terms = 0: the int8 W8A8 operator (int8 rows, per-row f32 factors; see A8GemmParams)
 int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream, int terms = 2);
 bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n);

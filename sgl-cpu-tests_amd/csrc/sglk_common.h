@@ -6,6 +6,21 @@
 
 #include "../../include/sglk.h"
 
+// Developer-only scaffolding -- timing ablations (WRONG results by design) and in-kernel time stamps -- exists only in
+// SGLK_DEV_ABLATE builds (`SGLK_DEV_ABLATE=1 python sgl-cpu-tests_amd/build.py` -> libsglk_dev.so, loaded through SGLK_LIB_PATH by
+// tools/tile_timeline.py).  In the product build every SGLK_ABL(bits, mask) is the literal `false` and SGLK_PP_ABL is 0: the
+// guarded statements compile to nothing and no ablation instantiation is reachable.
+#ifdef SGLK_DEV_ABLATE
+#define SGLK_ABL(bits, mask) ((((int)(bits)) & (mask)) != 0)
+#else
+#define SGLK_ABL(bits, mask) false
+#endif
+#if defined(SGLK_DEV_ABLATE) && defined(SGLK_PP_ABLATE)   // attention.hip: -DSGLK_PP_ABLATE=bits in a developer build
+#define SGLK_PP_ABL SGLK_PP_ABLATE
+#else
+#define SGLK_PP_ABL 0
+#endif
+
 namespace sglk {
 
 // ---- error plumbing ---------------------------------------------------------------------------------

@@ -155,7 +155,7 @@ def test_fused_experts_a8_scale_extremes(ops, a8):
     check_a8(out, moe_a8.fused_experts_a8(*args), c_oracle.fused_experts_fp8(*args), "scale extremes")
 
 
-@pytest.mark.parametrize("M", [1000, 4096])
+@pytest.mark.parametrize("M", [1000, 4096, 16384])
 def test_fused_experts_a8_qwen3_full_experts(ops, a8, M):
     """Qwen3-30B-A3B expert dims, all 128 experts; sampled tokens against the quantised-arithmetic oracle."""
     from sgl_kernel import _lib
@@ -176,41 +176,3 @@ def test_fused_experts_a8_qwen3_full_experts(ops, a8, M):
     sample = torch.arange(0, M, max(1, M // 48))[:48]
     args = (a[sample].cpu(), w1.cpu(), w2.cpu(), w1s.cpu(), w2s.cpu(), (bn, bk), tw[sample].cpu(), ids[sample].cpu())
     check_a8(out[sample], moe_a8.fused_experts_a8(*args), c_oracle.fused_experts_fp8(*args), f"qwen3 M={M}")
-
-
-# ---- the same mode on the 128-token kernel (moe_gemm_fp8w_s128.hip with one e4m3 term; SGLK_A8_S128=1) ---------------------
-
-@pytest.mark.parametrize("name", ["m1212_n512_k1024_e8_t2", "masked_m300_n256_k512_e16_t8", "qwen3dims_m96_e8_t8"])
-def test_a8_on_the_128_token_kernel_small_shapes(ops, a8, knob, name):
-    """Same formats, same quantiser, the same sequence of scaled MFMAs per accumulator as moe_gemm_a8.hip: within the stated
-    tolerance of the quantised-arithmetic oracle, run-to-run identical, and BIT-IDENTICAL to the 256-row a8 kernels."""
-    from sgl_kernel import _lib
-    case = next(c for c in recipes.MOE_FP8_CASES if c[0] == name)
-    _, M, N, K, E, topk, bn, bk, masked, seed, _full = case
-    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, masked, seed)
-    knob(SGLK_A8_S128=1)
-    out = run(ops, inp, (bn, bk))
-    assert (a8.last_path & _lib.PATH_FP8_ACT) and (a8.last_path & _lib.PATH_TILE_MASK) == 128
-    args = (inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
-    check_a8(out, moe_a8.fused_experts_a8(*args), c_oracle.fused_experts_fp8(*args), name + " (s128)")
-    assert torch.equal(out, run(ops, inp, (bn, bk))), "run-to-run bit identity"
-    knob(SGLK_A8_S128=0)
-    ref_k = run(ops, inp, (bn, bk))
-    assert (a8.last_path & _lib.PATH_TILE_MASK) == 256
-    assert torch.equal(out, ref_k), "a8 on 128-token tiles != a8 on 256-token tiles"
-
-
-@pytest.mark.parametrize("M", [4096, 16384])
-def test_a8_on_the_128_token_kernel_qwen3(ops, a8, knob, M):
-    from sgl_kernel import _lib
-    import test_moe_fp8_bench_path_gpu as bp
-    q = bp.make_qwen3(ops)
-    a, tw, ids = bp.routed_inputs(M, 300 + M)
-    knob(SGLK_A8_S128=1)
-    out = bp.call(ops, q, a, tw, ids)
-    assert (a8.last_path & _lib.PATH_FP8_ACT) and (a8.last_path & _lib.PATH_TILE_MASK) == 128
-    sample = torch.arange(0, M, max(1, M // 48))[:48]
-    args = (a[sample].cpu(), q["w1"], q["w2"], q["w1s"].cpu(), q["w2s"].cpu(), (bp.BN, bp.BK), tw[sample].cpu(), ids[sample].cpu())
-    check_a8(out[sample], moe_a8.fused_experts_a8(*args), c_oracle.fused_experts_fp8(*args), f"qwen3 M={M} (s128)")
-    knob(SGLK_A8_S128=0)
-    assert torch.equal(out, bp.call(ops, q, a, tw, ids)), "a8 on 128-token tiles != a8 on 256-token tiles"
