@@ -60,6 +60,7 @@ void read_env() {
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
     k.s128 = env_int("SGLK_S128", -1);
     k.i8_s128 = env_int("SGLK_I8_S128", -1);
+    k.s128_prio = env_int("SGLK_S128_PRIO", -1);
     k.dense_s128 = env_int("SGLK_DENSE_S128", -1);
     k.ar_wait_ms = env_int("SGLK_AR_WAIT_MS", 0);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);

@@ -110,6 +110,7 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 #define SGLK_STAMP(i) do { } while (0)
 #endif
 
+    if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
     float* sc = reinterpret_cast<float*>(smem + kScaleOff);          // sc[piece][kb]
     unsigned char* xs_tab = smem + kXsOff;                             // xs_tab[kb][token row]
     int* slot_tab = reinterpret_cast<int*>(smem + kRowTabOff);
@@ -365,6 +366,8 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
 
     int buf = 0;
     SGLK_STAMP(19);
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(1);        // the main loop outranks a co-resident workgroup's prologue /
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(0);   // epilogue (1), or the other way round (2: A/B only)
 #ifdef SGLK_DEV_ABLATE
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -551,6 +554,8 @@ SGLK_DEV void run_tile(const A8GemmParams& p, unsigned char* smem, const TileId 
     }
 #undef SGLK_FENCE
     SGLK_STAMP(20);
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(0);
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(1);
 #ifdef SGLK_DEV_ABLATE
     if (p.dbg && tid == 0) {   // shader clocks / 100 MHz ticks over the main loop -> the clock the chip held
         p.dbg[32 * L + 0] = __builtin_amdgcn_s_memtime() - clk0;
@@ -935,7 +940,11 @@ bool moe_gemm_fp8w_s128_ok(int N, int K, int block_n) {
            block_n % 32 == 0;
 }
 
-int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p, int max_mtiles, hipStream_t stream, int terms) {
+int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p_in, int max_mtiles, hipStream_t stream, int terms) {
+    A8GemmParams p = p_in;
+    // wave priority: GEMM-2's short main loop gains ~3 % when it outranks the co-resident workgroup's prologue / epilogue
+    // (0.391 -> 0.380 ms at 16384 tokens); GEMM-1 is indifferent (profiles/r03_ab_s128_prio.txt).  SGLK_S128_PRIO=0 / 1 / 2 forces.
+    p.prio = knobs().s128_prio >= 0 ? knobs().s128_prio : (mode == MODE_DOWN ? 1 : 0);
     if ((int64_t)max_mtiles * p.n_tiles == 0) return SGLK_OK;
     // groups of 8 m-tiles dealt round-robin to the 8 XCDs (see the kernel): every XCD gets the same number of workgroups
     const int64_t groups = ceil_div(max_mtiles, 8), groups_per_xcd = ceil_div(groups, 8);

@@ -81,6 +81,7 @@ struct A8GemmParams {
     int out_s_stride;
     const float* topk_weights;    // DOWN
     int max_mtiles;               // s128 kernel: entries of tile_info that may be read (the launch's m-tile bound)
+    int prio;                     // s128 kernel: wave priority experiment (knobs().s128_prio; 0 = none)
     // s128 kernel, int8 W8A8 (terms = 0): x / ic1 rows are int8 in natural k order, w = pack.hip's int8 tiles, w_scale = per weight
     // row [E][scale_rows]; one f32 factor per x row instead of xs; GATE_UP writes int8 ic1 + out_scale_f32[position] and needs
     // row_amax [M * topk] (zeroed) and arrivals [max_mtiles] (zeroed) for the per-token maximum across the m-tile's workgroups
