@@ -40,8 +40,8 @@ def routing(M, E, topk, kind, g):
 
 
 for it in range(iters):
-    N = rng.choice([128, 256, 384, 512, 768])
-    K = rng.choice([128, 256, 512, 1024, 2048])
+    N = rng.choice([128, 256, 384, 512, 768, 1024])
+    K = rng.choice([128, 256, 512, 1024, 2048, 4096, 7168])      # up to 56 K blocks: the 128-token kernel's 64-block scale tables
     E = rng.choice([1, 2, 8, 16, 64])
     topk = rng.choice([t for t in (1, 2, 4, 8) if t <= E])
     M = rng.choice([1, 2, 3, 4, 7, 16, 33, 64, 100, 257, 600, 1500, 3000]) if E <= 16 else rng.choice([1, 4, 16, 64, 300, 1200])
