@@ -252,7 +252,11 @@ int launch_moe_align_split(const int32_t* topk_ids, int32_t M, int32_t E, int32_
     int nbits = 0;
     while ((1 << nbits) < E) ++nbits;
     const int max_tiles = sglk_moe_max_tiles(M, E, topk, tile_m);
-    if (tail_max <= 0 && S <= kSmallSlots && E <= kSmallMaxE && !knobs().align_3pass) {
+    // one launch for small inputs -- unless a row job wants to ride in the placing launch (then count + place are two launches
+    // either way and the job's own launch is saved), and only up to 6144 slots: at 8192 the single 1024-thread workgroup takes
+    // 28 us against 20 us for count + place (profiles/r03_v3_stage_sweep.json: M = 1024 vs 1536)
+    const bool has_job = job && job->rows > 0;
+    if (tail_max <= 0 && !has_job && S <= 6144 && S <= kSmallSlots && E <= kSmallMaxE && !knobs().align_3pass) {
         hipLaunchKernelGGL(moe_align_small_kernel, dim3(1), dim3(1024), 0, s, topk_ids, S, E, nbits, tile_m, max_tiles,
                            sorted_slot, expert_off, tile_info, num_tiles, zero16);
         SGLK_CHECK_LAUNCH("moe_align");
