@@ -137,6 +137,20 @@ def test_a8_deviation_from_the_reference_oracle_is_pinned(ops, a8, name):
     assert rel < 0.08 and torch.isfinite(out).all()
 
 
+def test_fused_experts_a8_long_reduction(ops, a8):
+    """56 K blocks in GEMM-1 (K = 7168, the reference bench's hidden size, bench_moe.py:144) and three in GEMM-2: the 64-block scale
+    tables of the 128-token kernel and the shortest odd rotation of its fragment sets."""
+    M, N, K, E, topk, bn, bk = 600, 384, 7168, 8, 2, 128, 128
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 9107)
+    args = (inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+    ref_q = moe_a8.fused_experts_a8(*args)
+    k = float(2.0 / ref_q.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    args = (inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+    out = run(ops, inp, (bn, bk))
+    check_a8(out, moe_a8.fused_experts_a8(*args), c_oracle.fused_experts_fp8(*args), "K = 7168")
+
+
 def test_fused_experts_a8_scale_extremes(ops, a8):
     """Block scales over 2^-12 .. 2^4 with random sign, a zero block, ragged expert loads (rows per expert far from 256)."""
     M, N, K, E, topk, bn, bk = 1531, 256, 512, 8, 4, 128, 128
