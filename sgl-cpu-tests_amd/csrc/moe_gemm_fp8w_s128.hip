@@ -39,6 +39,10 @@ typedef __attribute__((ext_vector_type(16))) int i32x16;
 namespace gs128 {
 
 constexpr int kBM = 128;
+#ifndef SGLK_S128_GROUP
+#define SGLK_S128_GROUP 8
+#endif
+constexpr int kTileGroup = SGLK_S128_GROUP;   // consecutive m-tiles dealt to one XCD (A/B: 4 and 16 measured the same or worse)
 constexpr int kStageX = kBM * 128;            // 16 KiB: 128 tokens x (hi 64 + lo 64) bytes
 constexpr int kRing = 4;
 constexpr int kMaxKB = 64;                    // reduction length <= 8192
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(256, 2) void moe_gemm_fp8w_s128_kernel(const A8Gemm
     // round trip less in every tile's prologue): the m-tiles are dealt to the 8 XCDs in groups of kGroup consecutive ones (about
     // one expert's worth at the headline shape), column tiles fastest inside a group, so that the column tiles of an m-tile share
     // its gathered rows and the m-tiles of an expert its weights inside one L2.  Workgroups past the last m-tile leave.
-    constexpr int kGroup = 8;
+    constexpr int kGroup = kTileGroup;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     int mt;
     TileId t;
@@ -947,11 +951,11 @@ int launch_moe_gemm_fp8w_s128(int mode, const A8GemmParams& p_in, int max_mtiles
     p.prio = knobs().s128_prio >= 0 ? knobs().s128_prio : (mode == MODE_DOWN ? 1 : 0);
     if ((int64_t)max_mtiles * p.n_tiles == 0) return SGLK_OK;
     // groups of 8 m-tiles dealt round-robin to the 8 XCDs (see the kernel): every XCD gets the same number of workgroups
-    const int64_t groups = ceil_div(max_mtiles, 8), groups_per_xcd = ceil_div(groups, 8);
-    int64_t blocks = groups_per_xcd * 8 * p.n_tiles * 8;
+    const int64_t groups = ceil_div(max_mtiles, gs128::kTileGroup), groups_per_xcd = ceil_div(groups, 8);
+    int64_t blocks = groups_per_xcd * 8 * p.n_tiles * gs128::kTileGroup;
     if (mode == MODE_PLAIN) {   // dense rows: super-tiles of 8 m-tiles x sn column tiles, dealt to the XCDs (see the kernel)
         const int64_t sn = p.n_tiles < 8 ? p.n_tiles : 8, supers = groups * ceil_div(p.n_tiles, sn);
-        blocks = ceil_div(supers, 8) * 8 * (8 * sn);
+        blocks = ceil_div(supers, 8) * 8 * (gs128::kTileGroup * sn);
     }
     if (p.max_mtiles != max_mtiles) SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_s128: max_mtiles not set in the parameter block");
     const int kblocks = p.C >> 7;
