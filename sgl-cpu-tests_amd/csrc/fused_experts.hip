@@ -292,7 +292,9 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
     if (s128) tile_m = 128;
     const bool a8s = a8;   // (the a8 request was checked against moe_gemm_fp8w_s128_ok's shape rules above)
     if (a8s) tile_m = 128;
-    const bool i8s = tuned_i8 && moe_gemm_fp8w_s128_ok(N, K, 32) && (knobs().i8_s128 >= 0 ? knobs().i8_s128 == 1 : kI8S128Default);
+    // (an m-tile's N / 128 GEMM-1 workgroups wait for each other in the epilogue: with many column tiles the first ones would hold
+    // their slots for a good part of a tile's time, so wide experts stay on the 256-row kernels + separate quantisation pass)
+    const bool i8s = tuned_i8 && moe_gemm_fp8w_s128_ok(N, K, 32) && N / 128 <= 16 && (knobs().i8_s128 >= 0 ? knobs().i8_s128 == 1 : kI8S128Default);
     if (i8s) tile_m = 128;
     // 256-row plan: the last of an expert's several tiles, when it has at most 96 rows, is taken out of the table and run on
     // the weight-streaming mid kernel, where it costs what its rows cost instead of a whole 256-row tile (M = 4096: 61 of 189
