@@ -61,6 +61,9 @@ void read_env() {
     k.s128 = env_int("SGLK_S128", -1);
     k.i8_s128 = env_int("SGLK_I8_S128", -1);
     k.s128_prio = env_int("SGLK_S128_PRIO", -1);
+    k.no_mid_narrow = env_set("SGLK_NO_MID_NARROW");
+    k.mid_nw = env_int("SGLK_MID_NW", 0);
+    k.mid_far = env_int("SGLK_MID_FAR", -1);
     k.dense_s128 = env_int("SGLK_DENSE_S128", -1);
     k.ar_wait_ms = env_int("SGLK_AR_WAIT_MS", 0);
     k.fp8_act = env_int("SGLK_FP8_ACT", 0);

@@ -39,6 +39,8 @@ struct Knobs {
     int s128 = -1;               // SGLK_S128: 1 / 0 = the split on 128-token tiles with two workgroups per CU (moe_gemm_fp8w_s128.hip) / never; unset = default
     int ar_wait_ms = 0;          // SGLK_AR_WAIT_MS: how long the direct all-reduce waits for a peer before it gives up (default 30000)
     int dense_s128 = -1;         // SGLK_DENSE_S128: 0 = dense fp8 / int8 GEMMs never on the 128-token kernel; 1 = from 128 rows; unset = from 1024 of its tiles
+    int mid_nw = 0, mid_far = -1; // SGLK_MID_NW (4 / 8), SGLK_MID_FAR (0 / 1): force the mid kernel's GEMM-1 workgroup width / far activation prefetch (A/B)
+    bool no_mid_narrow = false;  // SGLK_NO_MID_NARROW: the mid kernel's GEMM-1 keeps 128 columns per workgroup at decode sizes too (A/B)
     int s128_prio = -1;          // SGLK_S128_PRIO: 0 = no wave priority in the 128-token kernel, 1 = s_setprio 1 inside its main loop, 2 = inside its prologue / epilogue; unset = 1 for GEMM-2 only
     int i8_s128 = -1;            // SGLK_I8_S128: 1 / 0 = large-M int8 W8A8 fused_experts on the 128-token kernel (terms = 0) / on gemm_i8_256.hip
     int fp8_act = 0;             // SGLK_FP8_ACT: 1 = opt-in a8 mode (fp8 activations on the block-scaled fp8 matrix cores)

@@ -58,8 +58,19 @@ struct TileCtx {
 // up), 1 for DOWN -- half the registers, so that two workgroups share a CU and one's prologue (tile table -> rows ->
 // first activations, three dependent round trips) and epilogue hide behind the other's stream; DOWN's reduction is
 // short (N = 768: six K blocks), so without that overlap the prologue is a third of its time.
-template <int MODE, int MT, bool ODD>
+// NW = waves per workgroup = 16-row weight tiles (GATE_UP: tile pairs) it covers: 8, or 4 / 2 for GATE_UP launches that would leave
+// most of the chip idle (decode-size batches: a CU streams ~36 GB/s whatever its ring depth, so what counts is how many CUs the
+// launch reaches -- the reference's decode shape, bench_moe.py:144, M = 4 / E = 256 / N = 384, is 96 workgroups of eight waves)
+// XD = K blocks the activations travel ahead of their use: 1 (two LDS buffers of 128 rows), or 3 with four buffers of the 32 rows a
+// decode-size tile has (MT = 2): there a K block is a few MFMAs, and with the activations only one block ahead every one of the
+// reduction's 56 blocks (K = 7168) waited out a global -> LDS round trip (0.9 us per block, 51 us per tile, whatever the ring depth
+// of the weights or the number of workgroups)
+template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1>
 SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
+    static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
+    static_assert(XD == 1 || (XD == 3 && MT == 2 && !ODD && MODE == MODE_GATE_UP), "the far prefetch is built for short GATE_UP tiles, even block counts");
+    constexpr int XB = XD + 1;                              // LDS buffers of the activations
+    constexpr int kXSz = XD == 1 ? kXBuf : MT * 16 * 256;   // bytes per buffer
     // DOWN: the rows' output slots and routing weights are two dependent round trips; they start here and wait in LDS
     // for the epilogue instead of being fetched by it
     int my_slot = -1;
@@ -76,7 +87,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    constexpr int XV = MT / 2;           // 1-KiB LDS-DMA pieces (4 rows x 256 B) of a K block per wave: MT*16 rows / 4 / 8
+    constexpr int XV = MT * 4 / NW;      // 1-KiB LDS-DMA pieces (4 rows x 256 B) of a K block per wave: MT*16 rows / 4 / NW
 
     // ---- activations: global -> LDS by DMA, no registers.  Piece q = wave*XV + j holds rows 4q .. 4q+3; lane l lands at
     //      byte 16*l of the piece (row 4q + (l>>4), chunk position l&15), so the swizzle is applied to the SOURCE chunk --
@@ -93,7 +104,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         xsrc[j] = p.x + xrow + ch * 8 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
-        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+        unsigned char* dst = lds + (kb % XB) * kXSz + wave * XV * 1024;
 #pragma unroll
         for (int j = 0; j < XV; ++j)
             __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + kb * 128), (lptr_t)(dst + j * 1024), 16, 0, 0);
@@ -108,10 +119,11 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     auto piece_ptr = [&](int kb, int j) __attribute__((always_inline)) { return c.wp[j >> 1] + (int64_t)(2 * kb + (j & 1)) * 1024; };
 
     // one 128-wide K block: ring slots PB*half .. = (tile0,k0) (tile0,k1) [(tile1,k0) (tile1,k1)]
-    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
-        // block kb+1's activations first, then the weight refills: loads retire in order, so "all but the newest PB
-        // loads have landed" at the end of the block means the activations (and the weights of block kb+1) are in
-        if (prefetch_x) x_dma(kb + 1);
+    // has_x: block kb+XD exists (its activations are requested here); prefetch_x: block kb+1 exists (sync at the end of this block)
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x, bool has_x) __attribute__((always_inline)) {
+        // block kb+XD's activations first, then the weight refills: loads retire in order, so "all but the newest ones of THIS
+        // block have landed" at the end of the block means the activations and the weights of block kb+1 are in
+        if (has_x) x_dma(kb + XD);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 w[TPW][4];   // [tile][k-step of the block]
 #pragma unroll
@@ -130,7 +142,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         float sc[TPW];
 #pragma unroll
         for (int a = 0; a < TPW; ++a) sc[a] = c.sc[a * kMaxKB + kb];
-        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+        const unsigned char* xb = lds + (kb % XB) * kXSz;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int xr = mt * 16 + r;
@@ -151,14 +163,24 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         if (prefetch_x) {   // the DMA target was last read in block kb-1, which every wave left before the barrier that closed it
             // the waits are builtins, not inline asm: the compiler's own wait-count pass sees them and knows the DMA has
             // landed; behind an opaque asm it re-waits with vmcnt(0) in front of the next LDS read and drains the ring
-            if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB)
-            else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+            if (XD == 1) {
+                if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB)
+                else __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+            } else {   // this block's own requests may stay in flight: XV pieces of block kb+XD, PB weight pieces of block kb+2
+                if (has_x && refill) __builtin_amdgcn_s_waitcnt(0x0F70 | (XV + PB));
+                else if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
             __builtin_amdgcn_s_barrier();
         }
     };
 
     if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];
     x_dma(0);
+    if (XD == 3) {   // (kblocks >= 4: launcher)
+        x_dma(1);
+        x_dma(2);
+    }
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): block 0's activations and the scale table
     int* slot_tab = reinterpret_cast<int*>(lds + kRowTabOff);
     float* tw_tab = reinterpret_cast<float*>(lds + kRowTabOff + kTM * 4);
@@ -171,21 +193,30 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     // s_waitcnt vmcnt(0) per piece and the ring degenerates): pairs of blocks with unconditional refills, then a tail of two
     // (even count) or three (odd count, e.g. N = 384 -> 3 blocks) blocks whose flags are literals too
     int kb = 0;
-    if (!ODD) {   // the parity of the block count is a template parameter: both tails in one kernel cost registers
-        for (; kb + 2 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+    if (XD == 3) {   // even count >= 4: pairs with everything on, then the last four blocks with literal flags
+        for (; kb + 5 <= c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, false, true);
-        block(kb + 1, 1, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, true, true, false);
+        block(kb + 2, 0, false, true, false);
+        block(kb + 3, 1, false, false, false);
+    } else if (!ODD) {   // the parity of the block count is a template parameter: both tails in one kernel cost registers
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
+        }
+        block(kb, 0, false, true, true);
+        block(kb + 1, 1, false, false, false);
     } else {
         for (; kb + 3 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, true, true);
-        block(kb + 1, 1, false, true);
-        block(kb + 2, 0, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, false, true, true);
+        block(kb + 2, 0, false, false, false);
     }
 
     // ---- epilogue: lane holds weight rows 4g..4g+3 of each tile for token r of every column tile ----------------------
@@ -199,7 +230,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
             uint2 v;
             v.x = pack_bf16x2(silu_f32(gt[0]) * up[0], silu_f32(gt[1]) * up[1]);
             v.y = pack_bf16x2(silu_f32(gt[2]) * up[2], silu_f32(gt[3]) * up[3]);
-            *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + c.ntile * 128 + wave * 16 + q4) = v;
+            *reinterpret_cast<uint2*>(p.out + (int64_t)(c.pos0 + tr) * p.out_stride + c.ntile * (NW * 16) + wave * 16 + q4) = v;
         } else if (MODE == MODE_PLAIN) {
             const int col = c.ntile * 128 + wave * 16 + q4;
             const f32x4 v4 = acc[0][mt];
@@ -347,8 +378,8 @@ SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCt
     store(1);
 }
 
-template <int MODE, bool ODD>
-__global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
+template <int MODE, bool ODD, int NW = 8, int XD = 1>
+__global__ __launch_bounds__(NW * 64, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
@@ -382,9 +413,9 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp
     c.kblocks = nsplit > 1 ? p.split_kblocks : p.C >> 7;
     c.kb0 = c.ksr * c.kblocks;
     const int ctiles = p.C >> 6;
-    if (MODE == MODE_GATE_UP) {          // workgroup = 128 ic1 columns: wave w -> columns ntile*128 + 16w .. +15
-        c.row16[0] = c.ntile * 8 + wave;
-        c.row16[1] = (p.n_half >> 4) + c.ntile * 8 + wave;
+    if (MODE == MODE_GATE_UP) {          // workgroup = NW * 16 ic1 columns: wave w -> columns ntile * (NW * 16) + 16w .. +15
+        c.row16[0] = c.ntile * NW + wave;
+        c.row16[1] = (p.n_half >> 4) + c.ntile * NW + wave;
     } else {                             // DOWN / PLAIN: 128 output columns, wave w -> columns ntile*128 + 16w .. +15
         c.row16[0] = c.ntile * 8 + wave;
         c.row16[1] = c.row16[0];
@@ -406,9 +437,9 @@ __global__ __launch_bounds__(512, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp
     c.sc = sc;
 
     const int mt = (c.rows + 15) >> 4;
-    if (mt <= 2) run<MODE, 2, ODD>(p, lds, c);
-    else if (mt <= 4) run<MODE, 4, ODD>(p, lds, c);
-    else run<MODE, 6, ODD>(p, lds, c);
+    if (mt <= 2) run<MODE, 2, ODD, NW, XD>(p, lds, c);
+    else if (mt <= 4) run<MODE, 4, ODD, NW>(p, lds, c);
+    else run<MODE, 6, ODD, NW>(p, lds, c);
 }
 
 // DOWN, two column tiles per workgroup (p.n_tiles = output columns / 256)
@@ -484,7 +515,33 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
     {                                                                                                              \
         if (kblocks & 1) MID_LAUNCH2(MD, true) else MID_LAUNCH2(MD, false)                                         \
     }
-    if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
+    // GATE_UP launches that reach only part of the chip (decode-size batches; same-box A/B at the reference's decode shape, M = 1 ... 32,
+    // profiles/r03_ab_mid_decode.txt): up to half the CUs -> 64 ic1 columns per workgroup (four waves) instead of 128; up to two
+    // rounds of the chip and an even block count -> the activations three K blocks ahead (run<>: NW, XD).  GEMM-1 at M = 1 / 4 / 8 /
+    // 16: 39.7 -> 27.7 / 51.4 -> 35.8 / 62.2 -> 59.6 / 125 -> 121 us.  SGLK_MID_NW / SGLK_MID_FAR force, SGLK_NO_MID_NARROW = as before.
+    int nw = 8;
+    const int cus = device_cu_count();
+    if (mode == MODE_GATE_UP && !knobs().no_mid_narrow) {
+        if (blocks * 2 <= cus) nw = 4;
+        if (knobs().mid_nw == 4 || knobs().mid_nw == 8) nw = knobs().mid_nw;
+    }
+    const bool far = mode == MODE_GATE_UP && !knobs().no_mid_narrow && !(kblocks & 1) && kblocks >= 4 &&
+                     (knobs().mid_far >= 0 ? knobs().mid_far == 1 : blocks < 2 * (int64_t)cus);
+    if (nw != 8 || far) {
+        MoeGemmParams q = p;
+        q.n_tiles = p.n_tiles * (8 / nw);
+        const int64_t nb = (int64_t)max_mtiles * q.n_tiles;
+#define MID_NARROW(OD, NWV, XDV)                                                                                                \
+    {                                                                                                                           \
+        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP, OD, NWV, XDV>), lds, "moe_gemm_fp8w_mid");            \
+        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MODE_GATE_UP, OD, NWV, XDV>), dim3((unsigned)nb), dim3(NWV * 64), lds, stream, q); \
+    }
+        if (nw == 8) MID_NARROW(false, 8, 3)
+        else if (kblocks & 1) MID_NARROW(true, 4, 1)
+        else if (far) MID_NARROW(false, 4, 3)
+        else MID_NARROW(false, 4, 1)
+#undef MID_NARROW
+    } else if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
     else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
     else MID_LAUNCH(MODE_PLAIN)
 #undef MID_LAUNCH

@@ -241,6 +241,33 @@ def test_fused_experts_fp8_rowmajor_weights_are_retiled_at_prefill_sizes(ops):
         check_close(rowmajor, ref, f"row-major M={M}")
 
 
+@pytest.mark.parametrize("shape", [(4, 384, 1024, 32, 8), (1, 384, 7168, 16, 8), (7, 128 * 3, 512, 8, 2), (20, 640, 768, 64, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_fused_experts_fp8_decode_sizes_on_narrow_workgroups(ops, knob, shape):
+    """Decode-size batches on the mid kernel (expert widths the 32-token stream kernel does not take, e.g. the reference's decode
+    bench shape N = 384, K = 7168, /root/reference/bench_moe.py:144): GEMM-1 on four-wave workgroups of 64 ic1 columns and with the
+    activations three K blocks ahead (moe_gemm_fp8w_mid.hip: NW, XD).  Every combination of the two, forced by knob, gives the SAME
+    bits (the arithmetic of a column does not depend on which workgroup owns it), and the oracle's values."""
+    from sgl_kernel import _lib, _ops
+    M, N, K, E, topk = shape
+    bn, bk = 128, 128
+    inp = recipes.moe_fp8_inputs(M, N, K, E, topk, bn, bk, False, 5150 + M + N)
+    ref = c_oracle.fused_experts_fp8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], (bn, bk), inp["topk_weight"], inp["topk_ids"])
+    k = float(2.0 / ref.abs().max())
+    inp["topk_weight"] = inp["topk_weight"] * k
+    outs = {}
+    for nw, far in ((8, 0), (8, 1), (4, 0), (4, 1)):
+        knob(SGLK_MOE_TILE_M=96, SGLK_MID_NW=nw, SGLK_MID_FAR=far)
+        outs[(nw, far)], _ = run_fp8(ops, inp, (bn, bk))
+        assert (_ops.last_path & _lib.PATH_TILE_MASK) == 96
+    check_close(outs[(8, 0)], ref * k, f"mid kernel, decode size {shape}")
+    for key, o in outs.items():
+        assert torch.equal(o, outs[(8, 0)]), f"workgroup width / prefetch distance {key} changed the result"
+    knob(SGLK_MOE_TILE_M=96, SGLK_MID_NW=None, SGLK_MID_FAR=None)
+    default, _ = run_fp8(ops, inp, (bn, bk))
+    assert torch.equal(default, outs[(8, 0)])
+
+
 def test_pack_weights_flag_is_a_hint(ops):
     """C-ABI: SGLK_MOE_PACK_WEIGHTS on a call that cannot use it -- weights already packed, a workspace sized WITHOUT the flag
     (sglk_fused_experts_workspace_bytes), M == 0 -- runs on the weights as given instead of failing with "unknown flags"

@@ -10,7 +10,7 @@ from sgl_kernel import _lib, _ops
 ops = torch.ops.sgl_kernel
 kind = sys.argv[1] if len(sys.argv) > 1 else "int8"
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-K, N, E, topk = 2048, 768, 128, 8
+K, N, E, topk = [int(v) for v in os.environ.get("SGLK_PROBE_SHAPE", "2048,768,128,8").split(",")]   # K,N,E,topk
 g = torch.Generator(device="cuda").manual_seed(6)
 a = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
 tw, ids = torch.topk(torch.softmax(torch.randn(M, E, device="cuda", generator=g), dim=-1), topk); ids = ids.to(torch.int32)
@@ -34,4 +34,9 @@ torch.cuda.synchronize()
 _ops.set_stage_timer(None)
 ms = (ctypes.c_float * _lib.NUM_STAGES)(); calls = ctypes.c_int32(0)
 L.sglk_stage_timer_read(timer, ms, ctypes.byref(calls))
-print(kind, "M", M, {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}, "sum", round(sum(ms), 4))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): f()
+e1.record(); torch.cuda.synchronize()
+print(kind, "M", M, "K,N,E,topk", (K, N, E, topk), {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}, "sum", round(sum(ms), 4),
+      "call (events around 20 calls)", round(e0.elapsed_time(e1) / 20, 4), "path", hex(_ops.last_path))
