@@ -37,9 +37,15 @@ struct Ctx {
 // MODE: PLAIN = dense rows (split-K, bias); GATE_UP / DOWN = the two grouped GEMMs of bf16 fused_experts at small / mid batch
 // sizes (gather by sorted_slot, gate + up tile per wave with SiLU*mul in registers; routing weight + scatter by slot), same
 // contract as gemm_bf16_256.hip's modes (oracle /root/reference/test_moe.py:22-54).
-template <int MODE, int MT, int TM, bool ODD>
+// NW = waves per workgroup (8; 4 for GATE_UP launches that reach at most half the CUs), XD = K blocks the activations travel ahead
+// (1; 3 with four LDS buffers of the 32 rows a decode-size tile has): as in moe_gemm_fp8w_mid.hip, where the two are measured
+template <int MODE, int MT, int TM, bool ODD, int NW = 8, int XD = 1>
 SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
+    static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
+    static_assert(XD == 1 || (XD == 3 && MT == 2 && !ODD && MODE == MODE_GATE_UP), "far prefetch: short GATE_UP tiles, even block counts");
     constexpr int kXBuf = TM * 256;
+    constexpr int XB = XD + 1;
+    constexpr int kXSz = XD == 1 ? kXBuf : MT * 16 * 256;
     constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
     // one K block of the wave's tile = 4 k-steps x 4 k pairs; k pair kp of the block sits kp * 128 B further
     auto load_block = [&](u32x4 (&dst)[TPW][4], int kb) __attribute__((always_inline)) {
@@ -63,7 +69,7 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    constexpr int XV = MT / 2;
+    constexpr int XV = MT * 4 / NW;
 
     const uint16_t* xsrc[XV];
 #pragma unroll
@@ -76,7 +82,7 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
         xsrc[j] = p.x + xrow + ch * 8 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
-        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+        unsigned char* dst = lds + (kb % XB) * kXSz + wave * XV * 1024;
 #pragma unroll
         for (int j = 0; j < XV; ++j)
             __builtin_amdgcn_global_load_lds((gptr_bm_t)(xsrc[j] + kb * 128), (lptr_bm_t)(dst + j * 1024), 16, 0, 0);
@@ -88,8 +94,9 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[a][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
-        if (prefetch_x) x_dma(kb + 1);
+    // has_x: block kb+XD exists (requested here); prefetch_x: block kb+1 exists (sync at the end of this block)
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x, bool has_x) __attribute__((always_inline)) {
+        if (has_x) x_dma(kb + XD);
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 w[TPW][4];
 #pragma unroll
@@ -98,7 +105,7 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
             for (int s = 0; s < 4; ++s) w[a][s] = __builtin_bit_cast(bf16x8, ring[half][a][s]);
         if (refill) load_block(ring[half], kb + 2);
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+        const unsigned char* xb = lds + (kb % XB) * kXSz;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int xr = mt * 16 + r;
@@ -111,7 +118,8 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
             }
         }
         if (prefetch_x) {
-            if (refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16 * TPW));   // all but the refill loads: the DMA has landed
+            if (XD == 3 && has_x && refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(XV + 16 * TPW));   // this block's own requests stay in flight
+            else if (refill) __builtin_amdgcn_s_waitcnt(vmcnt_imm(16 * TPW));   // all but the refill loads: the DMA has landed
             else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
             __builtin_amdgcn_s_barrier();
         }
@@ -119,6 +127,10 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
 
     if (MODE == MODE_DOWN && my_slot >= 0) my_tw = p.topk_weights[my_slot];
     x_dma(0);
+    if (XD == 3) {
+        x_dma(1);
+        x_dma(2);
+    }
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
     int* slot_tab = reinterpret_cast<int*>(lds + 2 * kXBuf);
     float* tw_tab = reinterpret_cast<float*>(lds + 2 * kXBuf + TM * 4);
@@ -128,25 +140,34 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     }
     __syncthreads();
     int kb = 0;
-    if (!ODD) {   // parity of the block count = template parameter (both tails in one kernel cost registers)
-        for (; kb + 2 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+    if (XD == 3) {   // even count >= 4: pairs with everything on, then the last four blocks with literal flags
+        for (; kb + 5 <= c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, false, true);
-        block(kb + 1, 1, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, true, true, false);
+        block(kb + 2, 0, false, true, false);
+        block(kb + 3, 1, false, false, false);
+    } else if (!ODD) {   // parity of the block count = template parameter (both tails in one kernel cost registers)
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
+        }
+        block(kb, 0, false, true, true);
+        block(kb + 1, 1, false, false, false);
     } else {                               // odd block counts (expert widths like 384): a three-block tail
         for (; kb + 3 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, true, true);
-        block(kb + 1, 1, false, true);
-        block(kb + 2, 0, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, false, true, true);
+        block(kb + 2, 0, false, false, false);
     }
 
     const int q4 = g * 4;
-    const int col = c.ntile * 128 + wave * 16 + q4;
+    const int col = c.ntile * (NW * 16) + wave * 16 + q4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tr = mt * 16 + r;
@@ -182,14 +203,14 @@ SGLK_DEV void run(const BmidParams& p, unsigned char* lds, const Ctx& c) {
     }
 }
 
-template <int MODE, int TM, bool ODD>
-__global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(const BmidParams p) {
+template <int MODE, int TM, bool ODD, int NW = 8, int XD = 1>
+__global__ __launch_bounds__(NW * 64, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(const BmidParams p) {
     constexpr int kTM = TM;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int n_tiles = p.N >> 7;
+    const int n_tiles = p.N / (NW * 16);
     const bool grouped = MODE != MODE_PLAIN;
     const int mtiles = grouped ? p.num_tiles[0] : (p.M + kTM - 1) / kTM;
     const int live = mtiles * n_tiles * nsplit;
@@ -217,16 +238,16 @@ __global__ __launch_bounds__(512, TM == 64 ? 4 : 2) void gemm_bf16_mid_kernel(co
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         // GATE_UP: tile 0 = gate rows, tile 1 = the matching up rows (N further); else one tile
-        const int R = (a && MODE == MODE_GATE_UP ? p.n_half : 0) + c.ntile * 128 + wave * 16 + (lane & 15);
+        const int R = (a && MODE == MODE_GATE_UP ? p.n_half : 0) + c.ntile * (NW * 16) + wave * 16 + (lane & 15);
         const int64_t dword = ((int64_t)(R >> 5) * (p.K >> 1) + (int64_t)c.kb0 * 64 + (lane >> 4) * 4) * 32 + (R & 31);
         c.wp[a] = wexp + dword * 4;
     }
     const int mt = (c.rows + 15) >> 4;
     constexpr int MTMAX = TM / 16;
-    if (mt <= 2) run<MODE, 2, TM, ODD>(p, lds, c);
-    else if (MTMAX == 4 || mt <= 4) run<MODE, 4, TM, ODD>(p, lds, c);
-    else if (MTMAX == 6 || mt <= 6) run<MODE, (MTMAX >= 6 ? 6 : 4), TM, ODD>(p, lds, c);
-    else run<MODE, (MTMAX >= 8 ? 8 : 4), TM, ODD>(p, lds, c);
+    if (mt <= 2) run<MODE, 2, TM, ODD, NW, XD>(p, lds, c);
+    else if (MTMAX == 4 || mt <= 4) run<MODE, 4, TM, ODD, NW>(p, lds, c);
+    else if (MTMAX == 6 || mt <= 6) run<MODE, (MTMAX >= 6 ? 6 : 4), TM, ODD, NW>(p, lds, c);
+    else run<MODE, (MTMAX >= 8 ? 8 : 4), TM, ODD, NW>(p, lds, c);
 }
 
 }  // namespace gbmid
@@ -283,7 +304,21 @@ int launch_moe_gemm_bf16_mid(int mode, const BmidParams& p, int max_mtiles, hipS
     const size_t lds = 2 * TM * 256 + 2 * TM * 4;
     const bool odd = (kblocks & 1) != 0;
     if (mode == MODE_GATE_UP) {
-        if (odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+        // decode-size launches: four-wave workgroups up to half the CUs, activations three K blocks ahead up to two rounds of the
+        // chip (policy and knobs of moe_gemm_fp8w_mid.hip)
+        const int cus = device_cu_count();
+        int nw = 8;
+        if (!knobs().no_mid_narrow) {
+            if (blocks * 2 <= cus) nw = 4;
+            if (knobs().mid_nw == 4 || knobs().mid_nw == 8) nw = knobs().mid_nw;
+        }
+        const bool far = !knobs().no_mid_narrow && !odd && kblocks >= 4 && (knobs().mid_far >= 0 ? knobs().mid_far == 1 : blocks < 2 * (int64_t)cus);
+        const int64_t nb = blocks * (8 / nw);
+        if (nw == 4 && odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, true, 4, 1>), dim3((unsigned)nb), dim3(256), lds, stream, p);
+        else if (nw == 4 && far) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, false, 4, 3>), dim3((unsigned)nb), dim3(256), lds, stream, p);
+        else if (nw == 4) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, false, 4, 1>), dim3((unsigned)nb), dim3(256), lds, stream, p);
+        else if (far) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, false, 8, 3>), dim3((unsigned)nb), dim3(512), lds, stream, p);
+        else if (odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
         else hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_GATE_UP, TM, false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
     } else {
         if (odd) hipLaunchKernelGGL((gbmid::gemm_bf16_mid_kernel<MODE_DOWN, TM, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
