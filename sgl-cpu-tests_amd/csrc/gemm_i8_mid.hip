@@ -11,6 +11,7 @@
 //   sees it) + one barrier per block;
 // * integer accumulation is exact; the epilogue applies (x_scale * acc) * w_scale in that order without contraction, like
 //   gemm_i8_256.hip, then SiLU*mul -> fp32 ic1 (GATE_UP) or the routing weight -> bf16 rows by slot (DOWN).
+#include "knobs.h"
 #include "sglk_common.h"
 #include "moe_internal.h"
 
@@ -34,8 +35,14 @@ struct Ctx {
     int row0[2];                  // first weight row of each tile (for the per-row scales)
 };
 
-template <int MODE, int MT, bool ODD>
+// NW = waves per workgroup (8; 4 for GATE_UP launches that reach at most half the CUs), XD = K blocks the activations travel ahead
+// (1; 3 with four LDS buffers of the 64 rows a short tile has): as in moe_gemm_fp8w_mid.hip, where the two are measured
+template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1>
 SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
+    static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
+    static_assert(XD == 1 || (XD == 3 && MT == 4 && !ODD && MODE == MODE_GATE_UP), "far prefetch: short GATE_UP tiles, even block counts");
+    constexpr int XB = XD + 1;
+    constexpr int kXSz = XD == 1 ? kXBuf : MT * 16 * 128;
     constexpr int TPW = MODE == MODE_GATE_UP ? 2 : 1;
     constexpr int PB = 2 * TPW;          // weight pieces per K block per wave
     u32x4 ring[2 * PB];                  // slot = block*PB + tile*2 + k half
@@ -45,7 +52,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    constexpr int XV = MT / 4;           // 1-KiB DMA pieces (8 rows x 128 B) of a K block per wave: MT*16 rows / 8 / 8
+    constexpr int XV = MT * 2 / NW;      // 1-KiB DMA pieces (8 rows x 128 B) of a K block per wave: MT*16 rows / 8 / NW
 
     const int8_t* xsrc[XV];
 #pragma unroll
@@ -58,7 +65,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
         xsrc[j] = p.x + xrow + ch * 16 + (int64_t)c.kb0 * 128;
     }
     auto x_dma = [&](int kb) __attribute__((always_inline)) {
-        unsigned char* dst = lds + (kb & 1) * kXBuf + wave * XV * 1024;
+        unsigned char* dst = lds + (kb % XB) * kXSz + wave * XV * 1024;
 #pragma unroll
         for (int j = 0; j < XV; ++j)
             __builtin_amdgcn_global_load_lds((gptr_im_t)(xsrc[j] + kb * 128), (lptr_im_t)(dst + j * 1024), 16, 0, 0);
@@ -70,8 +77,9 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[a][mt] = (i32x4){0, 0, 0, 0};
 
-    auto block = [&](int kb, int half, bool refill, bool prefetch_x) __attribute__((always_inline)) {
-        if (prefetch_x) x_dma(kb + 1);
+    // has_x: block kb+XD exists (requested here); prefetch_x: block kb+1 exists (sync at the end of this block)
+    auto block = [&](int kb, int half, bool refill, bool prefetch_x, bool has_x) __attribute__((always_inline)) {
+        if (has_x) x_dma(kb + XD);
         __builtin_amdgcn_sched_barrier(0);
         i32x4 w[TPW][2];
 #pragma unroll
@@ -85,7 +93,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
                 ring[half * PB + j] = *reinterpret_cast<const u32x4*>(c.wp[j >> 1] + (int64_t)(2 * (kb + 2) + (j & 1)) * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned char* xb = lds + (kb & 1) * kXBuf;
+        const unsigned char* xb = lds + (kb % XB) * kXSz;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int xr = mt * 16 + r;
@@ -98,31 +106,45 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
             }
         }
         if (prefetch_x) {
-            if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB): all but the refills -> the DMA has landed
+            if (XD == 3 && has_x && refill) __builtin_amdgcn_s_waitcnt(0x0F70 | (XV + PB));   // this block's own requests stay in flight
+            else if (refill) __builtin_amdgcn_s_waitcnt(0x0F70 | PB);   // vmcnt(PB): all but the refills -> the DMA has landed
             else __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_s_barrier();
         }
     };
 
     x_dma(0);
+    if (XD == 3) {
+        x_dma(1);
+        x_dma(2);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     int kb = 0;
-    if (!ODD) {
-        for (; kb + 2 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+    if (XD == 3) {   // even count >= 4: pairs with everything on, then the last four blocks with literal flags
+        for (; kb + 5 <= c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, false, true);
-        block(kb + 1, 1, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, true, true, false);
+        block(kb + 2, 0, false, true, false);
+        block(kb + 3, 1, false, false, false);
+    } else if (!ODD) {
+        for (; kb + 2 < c.kblocks; kb += 2) {
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
+        }
+        block(kb, 0, false, true, true);
+        block(kb + 1, 1, false, false, false);
     } else {
         for (; kb + 3 < c.kblocks; kb += 2) {
-            block(kb, 0, true, true);
-            block(kb + 1, 1, true, true);
+            block(kb, 0, true, true, true);
+            block(kb + 1, 1, true, true, true);
         }
-        block(kb, 0, true, true);
-        block(kb + 1, 1, false, true);
-        block(kb + 2, 0, false, false);
+        block(kb, 0, true, true, true);
+        block(kb + 1, 1, false, true, true);
+        block(kb + 2, 0, false, false, false);
     }
 
     // ---- epilogue: lane holds weight rows 4g..4g+3 of each tile for row r of every column tile ----------------------------
@@ -130,7 +152,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     const float* wsc = p.w_scale + (int64_t)c.e * p.scale_rows;
     const float4 ws0 = *reinterpret_cast<const float4*>(wsc + c.row0[0] + q4);
     const float4 ws1 = TPW == 2 ? *reinterpret_cast<const float4*>(wsc + c.row0[1] + q4) : ws0;
-    const int col = c.ntile * 128 + wave * 16 + q4;
+    const int col = c.ntile * (NW * 16) + wave * 16 + q4;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int tr = mt * 16 + r;
@@ -181,8 +203,8 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     }
 }
 
-template <int MODE, bool ODD>
-__global__ __launch_bounds__(512, 2) void gemm_i8_mid_kernel(const I8GemmParams p) {
+template <int MODE, bool ODD, int NW = 8, int XD = 1>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_i8_mid_kernel(const I8GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,13 +229,13 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_mid_kernel(const I8GemmParams 
     c.kb0 = c.ksr * c.kblocks;
     const int ctiles = p.K >> 6;
     // both modes: 128 output columns per workgroup, wave w -> columns ntile*128 + 16w .. +15 (GATE_UP: gate + matching up tile)
-    c.row0[0] = c.ntile * 128 + wave * 16;
+    c.row0[0] = c.ntile * (NW * 16) + wave * 16;
     c.row0[1] = (MODE == MODE_GATE_UP ? p.n_half : 0) + c.row0[0];
     const unsigned char* wexp = p.w + (int64_t)c.e * p.w_bytes;
     c.wp[0] = wexp + ((int64_t)(c.row0[0] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
     c.wp[1] = wexp + ((int64_t)(c.row0[1] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
-    if (c.rows <= 64) run<MODE, 4, ODD>(p, lds, c);
-    else run<MODE, 8, ODD>(p, lds, c);
+    if (c.rows <= 64) run<MODE, 4, ODD, NW, XD>(p, lds, c);
+    else run<MODE, 8, ODD, NW>(p, lds, c);
 }
 
 // out[r][c] = cast((x_scale[r] * (float)(sum over ranges of the int32 partials)) * w_scale[c] + bias[c]): the integer sum is
@@ -359,8 +381,28 @@ int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStrea
     const bool odd = (kblocks & 1) != 0;
     const size_t lds = gimid::kLds;
 #define I8MID(MD, OD) hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p)
-    if (mode == MODE_GATE_UP) { if (odd) I8MID(MODE_GATE_UP, true); else I8MID(MODE_GATE_UP, false); }
-    else { if (odd) I8MID(MODE_DOWN, true); else I8MID(MODE_DOWN, false); }
+    if (mode == MODE_GATE_UP) {
+        // decode-size launches: four-wave workgroups up to half the CUs, activations three K blocks ahead up to two rounds of the
+        // chip (policy and knobs of moe_gemm_fp8w_mid.hip)
+        const int cus = device_cu_count();
+        int nw = 8;
+        if (!knobs().no_mid_narrow) {
+            if (blocks * 2 <= cus) nw = 4;
+            if (knobs().mid_nw == 4 || knobs().mid_nw == 8) nw = knobs().mid_nw;
+        }
+        const bool far = !knobs().no_mid_narrow && !odd && kblocks >= 4 && (knobs().mid_far >= 0 ? knobs().mid_far == 1 : blocks < 2 * (int64_t)cus);
+        I8GemmParams q = p;
+        q.n_tiles = p.n_tiles * (8 / nw);
+        const int64_t nb = (int64_t)max_mtiles * q.n_tiles;
+#define I8MIDN(OD, NWV, XDV) hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MODE_GATE_UP, OD, NWV, XDV>), dim3((unsigned)nb), dim3(NWV * 64), lds, stream, q)
+        if (nw == 4 && odd) I8MIDN(true, 4, 1);
+        else if (nw == 4 && far) I8MIDN(false, 4, 3);
+        else if (nw == 4) I8MIDN(false, 4, 1);
+        else if (far) I8MIDN(false, 8, 3);
+        else if (odd) I8MID(MODE_GATE_UP, true);
+        else I8MID(MODE_GATE_UP, false);
+#undef I8MIDN
+    } else { if (odd) I8MID(MODE_DOWN, true); else I8MID(MODE_DOWN, false); }
 #undef I8MID
     SGLK_CHECK_LAUNCH("gemm_i8_mid");
     return SGLK_OK;
