@@ -68,7 +68,9 @@ struct TileCtx {
 template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1>
 SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
     static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
-    static_assert(XD == 1 || (XD == 3 && MT == 2 && !ODD && MODE == MODE_GATE_UP), "the far prefetch is built for short GATE_UP tiles, even block counts");
+    // (ODD with XD = 3: a reduction of exactly three blocks -- expert width 384 in DOWN -- all of whose activations are requested up front)
+    static_assert(XD == 1 || (XD == 3 && MT == 2 && ((!ODD && MODE == MODE_GATE_UP) || (ODD && MODE == MODE_DOWN))),
+                  "the far prefetch is built for short tiles: GATE_UP with even block counts, DOWN with three blocks");
     constexpr int XB = XD + 1;                              // LDS buffers of the activations
     constexpr int kXSz = XD == 1 ? kXBuf : MT * 16 * 256;   // bytes per buffer
     // DOWN: the rows' output slots and routing weights are two dependent round trips; they start here and wait in LDS
@@ -193,7 +195,11 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     // s_waitcnt vmcnt(0) per piece and the ring degenerates): pairs of blocks with unconditional refills, then a tail of two
     // (even count) or three (odd count, e.g. N = 384 -> 3 blocks) blocks whose flags are literals too
     int kb = 0;
-    if (XD == 3) {   // even count >= 4: pairs with everything on, then the last four blocks with literal flags
+    if (XD == 3 && ODD) {   // exactly three blocks (launcher), all three requested in the prologue
+        block(0, 0, true, true, false);
+        block(1, 1, false, true, false);
+        block(2, 0, false, false, false);
+    } else if (XD == 3) {   // even count >= 4: pairs with everything on, then the last four blocks with literal flags
         for (; kb + 5 <= c.kblocks; kb += 2) {
             block(kb, 0, true, true, true);
             block(kb + 1, 1, true, true, true);
@@ -542,7 +548,10 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
         else MID_NARROW(false, 4, 1)
 #undef MID_NARROW
     } else if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
-    else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
+    else if (mode == MODE_DOWN && kblocks == 3 && !knobs().no_mid_narrow) {   // short tiles request their three K blocks of activations up front
+        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN, true, 8, 3>), lds, "moe_gemm_fp8w_mid");
+        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN, true, 8, 3>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+    } else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
     else MID_LAUNCH(MODE_PLAIN)
 #undef MID_LAUNCH
 #undef MID_LAUNCH2
