@@ -164,7 +164,10 @@ struct Core {
     // DV here is the width of the V slice this wave accumulates; dv0 = its first column inside the V image, whose rows
     // are VROW elements wide (0 = DV, i.e. the wave owns the whole width)
     // NKT = 16-key tiles this wave takes from the image (4 = all 64 keys; 2 = the 32 keys from row k0, decode kernel)
-    template <bool V_ALIAS, int VROW = 0, int NKT = 4>
+    // ASM_TR: the transposed V reads are inline asm with hand-counted lgkmcnt waits.  The compiler does not know what the
+    // ds_read_tr builtin may alias and puts an s_waitcnt vmcnt(0) in front of the first one whenever LDS-DMA writes are pending:
+    // in the decode kernel that drained the NEXT tiles' rows in the middle of every tile.
+    template <bool V_ALIAS, int VROW = 0, int NKT = 4, bool ASM_TR = false>
     SGLK_DEV void tile(const unsigned char* klds, const unsigned char* vlds, int key_base, const int (&limit)[QT],
                        float scale_log2e, float logit_cap, int lane, int dv0 = 0, int k0 = 0) {
         int lim_min = limit[0];
@@ -265,6 +268,42 @@ struct Core {
         }
         // ---- O^T += V^T . P ----
         const int q = r >> 2, pp = r & 3;   // transposed read: lane supplies row q, columns 4pp.. of its group's 4x16 block
+        if constexpr (ASM_TR) {
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            constexpr int NI = VT * (NKT / 2);
+            s16x4 lo[2], hi[2];
+            auto rd = [&](int i, s16x4& l, s16x4& h) {
+                const int t = i / (NKT / 2), ss = i - t * (NKT / 2);
+                const int row0 = k0 + ss * 32 + g * 4 + q, row1 = row0 + 16;
+                const int col = dv0 + t * 16 + pp * 4;
+                const int ch = col >> 3, sub = (col & 7) * 2;
+                const unsigned a0 = (unsigned)(size_t)(lds_s16x4_ptr)(vlds + row0 * (VW * 2) + ((ch ^ (row0 & VMASK)) << 4) + sub);
+                const unsigned a1 = (unsigned)(size_t)(lds_s16x4_ptr)(vlds + row1 * (VW * 2) + ((ch ^ (row1 & VMASK)) << 4) + sub);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l) : "v"(a0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h) : "v"(a1));
+            };
+            rd(0, lo[0], hi[0]);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                s16x4& l = lo[i & 1];
+                s16x4& h = hi[i & 1];
+                if (i + 1 < NI) {
+                    rd(i + 1, lo[(i + 1) & 1], hi[(i + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(l), "+v"(h));     // all but the two reads just issued
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l), "+v"(h));
+                }
+                s16x8 vv;
+                vv[0] = l[0]; vv[1] = l[1]; vv[2] = l[2]; vv[3] = l[3];
+                vv[4] = h[0]; vv[5] = h[1]; vv[6] = h[2]; vv[7] = h[3];
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                const int t = i / (NKT / 2), ss = i - t * (NKT / 2);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    o[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qt][ss], o[qt][t], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
 #pragma unroll
@@ -960,6 +999,15 @@ struct DecodeParams {
     const int64_t* b_seq_len;
     int HQ, HKV, splits, logit_splits, v_alias;   // splits used / depth of the caller's scratch
     float sm_scale, logit_cap;
+    int nt;                 // cache rows are read non-temporal
+    // fold_write: the new token's rows (k_buffer[loc[b]] = key[b], v_buffer[loc[b]] = value[b]) are written by the attention
+    // kernel itself -- EVERY workgroup writes the rows of its kv head for all B requests before it requests anything, so whatever
+    // cache row a page table names (another request's new row included) holds the new bytes by the time it is read
+    const unsigned short *key, *value;
+    const void* loc;
+    int64_t key_s0, key_s1, val_s0, val_s1;
+    int loc_is64, B, fold_write;
+    int abl;                // developer build only (SGLK_ABL): 1 = no tile arithmetic, 2 = no row requests after the prologue
 };
 
 // LDS-DMA staging of one 64-key tile (no registers, asynchronous): the image is written linearly, 1 KiB per wave
@@ -971,27 +1019,28 @@ struct TileDma {
     static constexpr int CH = WIDTH / 8;
     static constexpr int N = (kKeys * CH + THREADS - 1) / THREADS;   // DMA instructions per wave per tile
     static_assert((kKeys * CH) % THREADS == 0, "the image must be a whole number of workgroup-wide DMA rounds");
-    // The page lookups of a tile and its DMA instructions are issued one loop iteration apart (decode kernel): loads
-    // retire in order, so a lookup issued behind DMA instructions cannot be consumed before those have landed -- with both in
-    // one call a tile cost three to four memory round trips before its last row was even requested.
-    SGLK_DEV static void lookup(int (&tok)[N], const KvSource& src, int p0, int nkeys, int wave, int lane) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int c = i * THREADS + wave * 64 + lane;
-            const int row = c / CH;
-            const int rr = row < nkeys ? row : nkeys - 1;
-            tok[i] = src.page_is64 ? (int)reinterpret_cast<const int64_t*>(src.page)[p0 + rr]
-                                   : reinterpret_cast<const int*>(src.page)[p0 + rr];
-        }
+    // Decode kernel: the cache rows (page-table entries) of a tile are themselves fetched by LDS-DMA -- ONE 256-byte instruction of
+    // one wave per tile, into a small ring of id tables -- a whole step before the tile's rows are requested, and the row
+    // requests read them from LDS.  (Per-lane lookups cost N loads and N registers per lane and tile; and loads retire in order,
+    // so a lookup queued behind the previous tile's rows could not be consumed before those had landed.)  Positions past `nkeys`
+    // repeat the last valid row.  An int64 table contributes its low words (cache rows are < 2^31).
+    SGLK_DEV static void lookup_dma(unsigned* ids, const KvSource& src, int p0, int nkeys, int lane) {
+        const int rr = lane < nkeys ? lane : nkeys - 1;
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(src.page) + (int64_t)(p0 + rr) * (src.page_is64 ? 8 : 4);
+        __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)ids, 4, 0, 0);
     }
-    SGLK_DEV static void issue_rows(unsigned char* lds, const KvSource& src, const int (&tok)[N], int wave, int lane) {
+    template <int AUX>   // 2 = non-temporal: rows that one workgroup reads once need not stay in L2 / the Infinity Cache
+    SGLK_DEV static void issue_rows(unsigned char* lds, const KvSource& src, const unsigned* ids, int wave, int lane) {
         constexpr int MASK = Swz<CH>::mask;
+        int tok[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) tok[i] = (int)ids[(i * THREADS + wave * 64 + lane) / CH];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int c = i * THREADS + wave * 64 + lane;
             const int row = c / CH, slot = c - row * CH;
             const unsigned short* g = src.buf + (int64_t)tok[i] * src.buf_stride_tok + ((slot ^ (row & MASK)) << 3);
-            __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * THREADS + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((dma_gptr_t)g, (dma_lptr_t)(lds + (i * THREADS + wave * 64) * 16), 16, 0, AUX);
         }
     }
     SGLK_DEV static void issue(unsigned char* lds, const KvSource& src, int p0, int nkeys, int wave, int lane) {
@@ -1075,48 +1124,93 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
         DmaK::issue(buf, ks, p0, nk, wave, lane);
         if (!V_ALIAS) DmaV::issue(buf + KB, vs, p0, nk, wave, lane);
     };
-    // double-buffered form: the cache rows (page lookups) of tile t+2 are fetched while tile t+1's rows fly and tile t is
-    // multiplied; K and V rows of a key share the lookup only when their chunk maps agree (D == DV)
-    int tokk[DmaK::N], tokv[V_ALIAS ? 1 : DmaV::N];
+    // Double-buffered form.  Tile t+2's rows are requested the moment every wave has left tile t's buffer -- BEFORE the wait
+    // for tile t+1 -- so that one to two tiles are in flight at all times (with the request placed behind that wait the CU
+    // had only tile t+1 in flight, while it multiplied and while it stalled: a tile cost a whole memory round trip, 4.6 TB/s
+    // at best).  The id table of tile t+3 is requested just before those rows (TileDma::lookup_dma), i.e. it has a whole step
+    // to arrive and never queues in front of rows that wait for it.
+    // Queue of a wave at the wait of tile t:  ... rows(t) | [ids(t+2)] rows(t+1)  -> s_waitcnt vmcnt(kDma) covers rows(t), ids(t+2).
+    unsigned* const idring = reinterpret_cast<unsigned*>(dyn_lds + (kDouble ? 2 : 1) * (KB + VB));   // 4 tables of 64 ids
     auto lookup = [&](int t) {
-        const int tt = t < ntiles ? t : ntiles - 1;          // past the end: re-read the last tile's ids (never used)
+        if (wave != 0) return;
+        const int tt = t < ntiles ? t : ntiles - 1;          // past the end: the last tile's ids again (never used)
         const int p0 = k_begin + tt * kKeys;
         const int nk = k_end - p0 < kKeys ? k_end - p0 : kKeys;
-        DmaK::lookup(tokk, ks, p0, nk, wave, lane);
-        if constexpr (!V_ALIAS) DmaV::lookup(tokv, vs, p0, nk, wave, lane);
+        DmaK::lookup_dma(idring + (t & 3) * kKeys, ks, p0, nk, lane);
     };
-    auto issue_rows = [&](unsigned char* buf) {
-        DmaK::issue_rows(buf, ks, tokk, wave, lane);
-        if constexpr (!V_ALIAS) DmaV::issue_rows(buf + KB, vs, tokv, wave, lane);
+    auto issue_rows = [&](int t, unsigned char* buf) {
+        const unsigned* ids = idring + (t & 3) * kKeys;
+        if (p.nt) {
+            DmaK::template issue_rows<2>(buf, ks, ids, wave, lane);
+            if constexpr (!V_ALIAS) DmaV::template issue_rows<2>(buf + KB, vs, ids, wave, lane);
+        } else {
+            DmaK::template issue_rows<0>(buf, ks, ids, wave, lane);
+            if constexpr (!V_ALIAS) DmaV::template issue_rows<0>(buf + KB, vs, ids, wave, lane);
+        }
     };
-    if (ntiles > 0) {
-        if (kDouble) {
+    auto compute = [&](int t, const unsigned char* cur) {
+        if (wave_active && !SGLK_ABL(p.abl, 1))
+            core.template tile<V_ALIAS, DV, 4 / KH, true>(cur, V_ALIAS ? cur : cur + KB, k_begin + t * kKeys, limit, scale_log2e,
+                                                          p.logit_cap, lane, dsl * DVW, kh * 32);
+    };
+    if constexpr (kDouble) {
+        static_assert(kDma <= 63, "the counted wait must fit s_waitcnt's vmcnt field");
+        unsigned char* const buf0 = dyn_lds;
+        unsigned char* const buf1 = dyn_lds + KB + VB;
+        if (ntiles > 0) {
             lookup(0);
-            issue_rows(dyn_lds);
             lookup(1);
-        } else {
-            issue(0, dyn_lds);
+            lookup(2);
         }
-    }
-    for (int t = 0; t < ntiles; ++t) {
-        unsigned char* cur = dyn_lds + (kDouble ? (t & 1) * (KB + VB) : 0);
-        if (kDouble) {
-            // every wave has left tile t-1 (whose buffer tile t+1 overwrites) before anyone passes this barrier; the wait
-            // also covers the lookups of tile t+1, issued right behind tile t's rows
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 1 < ntiles) {
-                issue_rows(dyn_lds + ((t + 1) & 1) * (KB + VB));
-                lookup(t + 2);
+        if (p.fold_write) {
+            // 16-byte chunks; V after K in program order like the reference's two assignments (MLA: v_buffer aliases k_buffer's
+            // first DV columns, and `value` wins there).  Identical bytes from every workgroup: the race is benign, and a
+            // workgroup's own stores have reached its XCD's L2 (vmcnt) before any wave of it reads a row.
+            constexpr int KC = D / 8, VC = DV / 8;
+            for (int i = threadIdx.x; i < p.B * (KC + VC); i += 256 * KH) {
+                const int b2 = i / (KC + VC), c = i - b2 * (KC + VC);
+                const int64_t tok = p.loc_is64 ? reinterpret_cast<const int64_t*>(p.loc)[b2] : (int64_t)reinterpret_cast<const int*>(p.loc)[b2];
+                if (c < KC) {
+                    if (V_ALIAS && c < VC) continue;              // overwritten by the value chunk below
+                    const uint4 v = *reinterpret_cast<const uint4*>(p.key + (int64_t)b2 * p.key_s0 + (int64_t)kvh * p.key_s1 + c * 8);
+                    *reinterpret_cast<uint4*>(const_cast<unsigned short*>(p.k_buf) + tok * p.kb_s0 + (int64_t)kvh * p.kb_s1 + c * 8) = v;
+                } else {
+                    const int cv = c - KC;
+                    const uint4 v = *reinterpret_cast<const uint4*>(p.value + (int64_t)b2 * p.val_s0 + (int64_t)kvh * p.val_s1 + cv * 8);
+                    *reinterpret_cast<uint4*>(const_cast<unsigned short*>(p.v_buf) + tok * p.vb_s0 + (int64_t)kvh * p.vb_s1 + cv * 8) = v;
+                }
             }
-        } else {
+        }
+        if (ntiles > 0 || p.fold_write) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (wave_active)
-            core.template tile<V_ALIAS, DV, 4 / KH>(cur, V_ALIAS ? cur : cur + KB, k_begin + t * kKeys, limit, scale_log2e,
-                                                    p.logit_cap, lane, dsl * DVW, kh * 32);
-        if (!kDouble) {
+        if (ntiles > 0) {
+            issue_rows(0, buf0);
+            if (ntiles > 1) issue_rows(1, buf1);
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            unsigned char* const cur = (t & 1) ? buf1 : buf0;
+            if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // bare s_barrier: __syncthreads()' fence would make the compiler drain vmcnt -- the rows in flight -- in front of it
+            __builtin_amdgcn_s_barrier();         // every wave's share of tile t has landed, and the id table of tile t+2
+            asm volatile("" ::: "memory");
+            compute(t, cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();         // every wave has left `cur`
+            asm volatile("" ::: "memory");
+            if (t + 2 < ntiles) {
+                lookup(t + 3);
+                if (!SGLK_ABL(p.abl, 2)) issue_rows(t + 2, cur);
+            }
+        }
+    } else {
+        if (ntiles > 0) issue(0, dyn_lds);
+        for (int t = 0; t < ntiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(t, dyn_lds);
             __syncthreads();                     // the single buffer is free again
             if (t + 1 < ntiles) issue(t + 1, dyn_lds);
         }
@@ -1380,6 +1474,22 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
                                a->v_buffer_stride[0], a->v_buffer_stride[1]};
     for (int64_t st : strides) SGLK_REQUIRE(st % 8 == 0, SGLK_ERR_SHAPE, "decode_attention: q/k/v strides must be multiples of 8 elements");
     hipStream_t s = (hipStream_t)stream;
+    // V aliases K when it is the same storage with the same strides (MLA: v = k[..., :DV])
+    const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
+                       a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
+    // The cache write rides in the attention kernel (DecodeParams::fold_write) while the rows every workgroup then has to write --
+    // all B requests' -- stay small: one launch and one kernel boundary less.  Measured on one box (profiles/r03_ab_decode.txt):
+    // MLA B = 1: 17.5 -> 15.5 us, GQA B = 8 x 8192 keys: 32.4 -> 30.8; neutral at GQA B = 16 x 2048 (8 MB written in all), 3 %
+    // SLOWER at MLA B = 40 x 1064 (46 KB per workgroup, 11 MB in all) and 5-8 % slower at GQA B = 64 x 4096 (2048 workgroups x
+    // 32 KB): hence the cap on the total.
+    // Needs 16-byte rows and the double-buffered kernel form.  SGLK_DEC_FOLD=0: always the separate launch.
+    const int64_t fold_bytes = (int64_t)a->B * (a->D + (alias ? 0 : a->DV)) * 2;   // per workgroup; every workgroup writes them
+    bool fold = knobs().dec_fold != 0 && fold_bytes <= 48 * 1024 && fold_bytes * a->B * a->HKV * a->splits <= (4ll << 20) &&
+                2 * ((size_t)kKeys * a->D * 2 + (alias ? 0 : (size_t)kKeys * a->DV * 2)) <= SGLK_DEC_DOUBLE_LIMIT;
+    for (int64_t st : {a->key_stride[0], a->key_stride[1], a->value_stride[0], a->value_stride[1]}) fold = fold && st % 8 == 0;
+    for (const void* ptr : {(const void*)a->key, (const void*)a->value, (const void*)a->k_buffer, (const void*)a->v_buffer})
+        fold = fold && ((uintptr_t)ptr % 16) == 0;
+    if (!fold)
     hipLaunchKernelGGL(kv_cache_write_kernel, dim3((unsigned)a->B, (unsigned)a->HKV), dim3(256), 0, s,
                        (unsigned short*)a->k_buffer, a->k_buffer_stride[0], a->k_buffer_stride[1], (unsigned short*)a->v_buffer,
                        a->v_buffer_stride[0], a->v_buffer_stride[1], (const unsigned short*)a->key, a->key_stride[0],
@@ -1414,15 +1524,21 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     p.splits = eff;
     p.logit_splits = a->splits;
     p.sm_scale = a->sm_scale; p.logit_cap = a->logit_cap;
-    // V aliases K when it is the same storage with the same strides (MLA: v = k[..., :DV])
-    const bool alias = a->v_buffer == a->k_buffer && a->v_buffer_stride[0] == a->k_buffer_stride[0] &&
-                       a->v_buffer_stride[1] == a->k_buffer_stride[1] && a->DV <= a->D;
+    p.abl = knobs().rescale_ablate;   // read by SGLK_DEV_ABLATE builds only
+    // Each cache row is read once, by one workgroup: the non-temporal policy keeps it from displacing anything in L2 / the Infinity
+    // Cache.  Measured on one box against the default policy (hipGraph replays, profiles/r03_ab_decode.txt): MLA B = 128 x 4096 keys
+    // 0.128 -> 0.120 ms, GQA B = 64 x 4096 0.110 -> 0.097 ms, and still 0.0278 -> 0.0253 ms at B = 40 x 1064, whose 49 MB would fit the
+    // Infinity Cache between replays.  SGLK_DEC_NT=0 turns it off.
+    p.nt = knobs().dec_nt != 0 ? 1 : 0;
+    p.key = (const unsigned short*)a->key; p.value = (const unsigned short*)a->value; p.loc = a->loc; p.loc_is64 = a->loc_is64;
+    p.key_s0 = a->key_stride[0]; p.key_s1 = a->key_stride[1]; p.val_s0 = a->value_stride[0]; p.val_s1 = a->value_stride[1];
+    p.B = a->B; p.fold_write = fold ? 1 : 0;
     const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)eff);
     const int group = a->HQ / a->HKV;
 #define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
     {                                                                                                              \
         constexpr size_t kb = (size_t)kKeys * DD * 2, vb = (AL) ? 0 : (size_t)kKeys * DDV * 2;                     \
-        constexpr size_t lds = (2 * (kb + vb) <= SGLK_DEC_DOUBLE_LIMIT) ? 2 * (kb + vb) : (kb + vb);                \
+        constexpr size_t lds = (2 * (kb + vb) <= SGLK_DEC_DOUBLE_LIMIT) ? 2 * (kb + vb) + 4 * kKeys * 4 : (kb + vb);  /* + id tables */ \
         constexpr int kh = DD >= 256 ? SGLK_DEC_KH_WIDE : 1;   /* wide heads: the tile's keys are split over two wave groups */ \
         SGLK_ENSURE_DYN_LDS((decode_attention_kernel<DD, DDV, AL, ND, kh>), lds, "decode_attention");           \
         hipLaunchKernelGGL((decode_attention_kernel<DD, DDV, AL, ND, kh>), grid, dim3(256 * kh), lds, s, p);       \

@@ -26,6 +26,8 @@ struct Knobs {
     int persist = -1;            // SGLK_PERSIST: 0 = one workgroup per tile, 1 = persistent; unset = by reduction length
     int max_wgs = 0;             // SGLK_MAX_WGS: cap on the persistent launches' workgroups (tests: forces many tiles per
                                  //               workgroup on small problems); 0 = one per CU
+    int dec_nt = -1;             // SGLK_DEC_NT: 1 / 0 = decode_attention's cache rows are read with / without the non-temporal policy (-1 = on)
+    int dec_fold = -1;           // SGLK_DEC_FOLD: 0 = decode_attention's cache write always as its own launch (-1 = folded when small)
     int dec_splits = 0;          // SGLK_DEC_SPLITS: KV splits decode_attention uses (0 = one round of workgroups, -1 = all the scratch has)
     int attn_nw = 0;             // SGLK_ATTN_NW: waves per extend-attention workgroup (4 / 8); 0 = by launch size
     int attn_pair = -1;          // SGLK_ATTN_PAIR: heavy + light causal query blocks in one workgroup (0 / 1); unset = by launch size

@@ -119,6 +119,60 @@ def test_decode_attention_ragged_lengths_and_int32_index(ops):
     assert (o.float().cpu() - ref).norm() / ref.norm() < 6e-3
 
 
+@pytest.mark.parametrize("shape", [(6, 22, 1, 576, 512, True), (7, 16, 4, 128, 128, False), (3, 8, 8, 64, 64, False)],
+                         ids=["mla", "gqa", "mha64"])
+def test_decode_attention_cache_write_inside_the_kernel(ops, knob, shape):
+    """The cache write rides in the attention kernel for small batches (DecodeParams::fold_write).  The reference writes ALL new
+    rows first and then attends (/root/reference/test_mla.py:27-28), and its own inputs draw `loc` anywhere in the pool (:96),
+    so a request's page list may name ANOTHER request's new row: here request b reads the slot request b+1 writes, at a known
+    position.  Checked against the oracle, and bit for bit against the separate-launch form (SGLK_DEC_FOLD=0) -- outputs, both
+    caches and the partial logits -- and with a `key` whose rows are not 16-byte aligned (falls back to the separate launch)."""
+    B, HQ, HKV, D, DV, alias = shape
+    L = 150
+    g = torch.Generator().manual_seed(77)
+    total = B * L + B
+    q = torch.randn(B, HQ, D, generator=g).bfloat16()
+    kb = torch.randn(total, HKV, D, generator=g).bfloat16()
+    vb = None if alias else torch.randn(total, HKV, DV, generator=g).bfloat16()
+    key = (torch.randn(B, HKV, D, generator=g) * 3).bfloat16()          # loud new rows: a stale read shows
+    value = None if alias else (torch.randn(B, HKV, DV, generator=g) * 3).bfloat16()
+    rtt = torch.randperm(B * L, generator=g).view(B, L)
+    loc = B * L + torch.arange(B)                                        # fresh slots ...
+    lens = torch.tensor([L - 7 * b for b in range(B)])
+    for b in range(B):
+        rtt[b, lens[b] - 1] = loc[b]                                     # ... the request's own new token last,
+        rtt[b, 3 + b] = loc[(b + 1) % B]                                 # and another request's new row in the middle
+    scale = 1.0 / D ** 0.5
+
+    def run(key_t, value_t):
+        kbd = kb.cuda()
+        vbd = kbd.narrow(2, 0, DV) if alias else vb.cuda()
+        o = torch.zeros(B, HQ, DV, dtype=torch.bfloat16, device="cuda")
+        logits = torch.zeros(B, HQ, 8, DV + 1, dtype=torch.float32, device="cuda")
+        ops.decode_attention_cpu(q.cuda(), kbd, vbd, o, key_t, key_t.narrow(2, 0, DV) if alias else value_t, loc.cuda(), logits,
+                                 rtt.cuda(), torch.arange(B).cuda(), lens.cuda(), scale, 0.0)
+        return o.cpu(), kbd.cpu(), vbd.cpu(), logits.cpu()
+
+    keyd, valued = key.cuda(), None if alias else value.cuda()
+    folded = run(keyd, valued)
+    knob(SGLK_DEC_FOLD=0)
+    separate = run(keyd, valued)
+    knob(SGLK_DEC_FOLD=None)
+    for a, b, what in zip(folded, separate, ("output", "k_buffer", "v_buffer", "partial logits")):
+        assert torch.equal(a, b), f"folded and separate cache write differ in the {what}"
+    # rows that start 2 bytes off a 16-byte boundary: the vector path must not be taken
+    pad = torch.zeros(B, HKV, D + 1, dtype=torch.bfloat16, device="cuda")
+    pad[:, :, 1:] = keyd
+    off = run(pad[:, :, 1:], valued)
+    assert torch.equal(off[0], folded[0]) and torch.equal(off[1], folded[1])
+    kb2 = kb.clone()
+    vb2 = kb2.narrow(2, 0, DV) if alias else vb.clone()
+    ref = oattn.decode_attention(q, kb2, vb2, key, key.narrow(2, 0, DV) if alias else value, loc, rtt, torch.arange(B), lens, scale)
+    assert torch.equal(folded[1], kb2) and torch.equal(folded[2], vb2), "cache contents after the call"
+    err = (folded[0].float() - ref).norm() / ref.norm()
+    assert err < 6e-3, f"relative RMS error {err:.2e}: a stale cache row would be far off"
+
+
 # ---- BASELINE.json config 3 at its own sizes (seqlen <= 8k): /root/reference/bench_extend.py:107-112, test_mla.py:178-186 ----
 @pytest.mark.parametrize("case", recipes.EXTEND_BIG_CASES, ids=lambda c: c[0])
 def test_extend_attention_bench_sizes(ops, case):
