@@ -51,6 +51,7 @@ void read_env() {
     k.dec_splits = env_int("SGLK_DEC_SPLITS", 0);
     k.dec_nt = env_int("SGLK_DEC_NT", -1);
     k.dec_fold = env_int("SGLK_DEC_FOLD", -1);
+    k.w_nt = env_int("SGLK_W_NT", -1);
     k.attn_nw = env_int("SGLK_ATTN_NW", 0);
     k.attn_order = env_int("SGLK_ATTN_ORDER", -1);
     k.attn_pair = env_int("SGLK_ATTN_PAIR", -1);

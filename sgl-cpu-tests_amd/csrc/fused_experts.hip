@@ -546,6 +546,9 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g1.out_stride = N;
         g1.topk_weights = nullptr;
         if (inline_align) { g1.inline_ids = a->topk_ids; g1.inline_slots = M * topk; g1.inline_experts = E; }
+        // decode-size kernels (stream / mid): non-temporal weight reads from 32 routed rows on (ld_stream16; SGLK_W_NT=0/1 forces)
+        const int w_nt = knobs().w_nt >= 0 ? knobs().w_nt : ((int64_t)M * topk >= 32 ? 1 : 0);
+        g1.w_nt = w_nt;
         // per-XCD tile tickets of the two persistent launches (8 counters each), zeroed per call by moe_align's last launch
         if (tile_m == 256) g1.tickets = (int*)(ws + w.tickets);
 #ifdef SGLK_DEV_ABLATE
@@ -560,6 +563,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
             t1.tile_info = (const int4*)tile_info_b;
             t1.num_tiles = num_tiles_b;
             t1.tickets = nullptr;
+            t1.w_nt = 0;              // the big launch reads the same experts: leave their weights cacheable
             MoeGemmParams t2{};
             t2.x = ic1;
             t2.x_stride = N;
@@ -622,6 +626,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         g2.block_n = a->block_n;
         g2.C = N;
         g2.n_half = 0;
+        g2.w_nt = w_nt;
         g2.tile_info = (const int4*)tile_info;
         g2.num_tiles = num_tiles;
         if (inline_align) { g2.inline_ids = a->topk_ids; g2.inline_slots = M * topk; g2.inline_experts = E; }
@@ -674,6 +679,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q1.sorted_slot = sorted_slot;
         q1.topk = topk;
         q1.n_half = N;
+        q1.w_nt = knobs().w_nt >= 0 ? knobs().w_nt : ((int64_t)M * topk >= 32 ? 1 : 0);   // as on the fp8 path
         rc = launch_gemm_i8_mid(MODE_GATE_UP, q1, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(2);
@@ -699,6 +705,7 @@ int fused_experts_impl(const sglk_fused_experts_args* a, void* stream, const Rou
         q2.sorted_slot = sorted_slot;
         q2.topk = topk;
         q2.topk_weights = a->topk_weights;
+        q2.w_nt = q1.w_nt;
         rc = launch_gemm_i8_mid(MODE_DOWN, q2, max_tiles, s);
         if (rc != SGLK_OK) return rc;
         mark(3);

@@ -37,7 +37,7 @@ struct Ctx {
 
 // NW = waves per workgroup (8; 4 for GATE_UP launches that reach at most half the CUs), XD = K blocks the activations travel ahead
 // (1; 3 with four LDS buffers of the 64 rows a short tile has): as in moe_gemm_fp8w_mid.hip, where the two are measured
-template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1>
+template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1, bool NT = false>
 SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
     static_assert(XD == 1 || (XD == 3 && MT == 4 && !ODD && MODE == MODE_GATE_UP), "far prefetch: short GATE_UP tiles, even block counts");
@@ -48,7 +48,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     u32x4 ring[2 * PB];                  // slot = block*PB + tile*2 + k half
 #pragma unroll
     for (int i = 0; i < 2 * PB; ++i)
-        ring[i] = *reinterpret_cast<const u32x4*>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
+        ring[i] = ld_stream16<NT>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -90,7 +90,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
         if (refill) {
 #pragma unroll
             for (int j = 0; j < PB; ++j)
-                ring[half * PB + j] = *reinterpret_cast<const u32x4*>(c.wp[j >> 1] + (int64_t)(2 * (kb + 2) + (j & 1)) * 1024);
+                ring[half * PB + j] = ld_stream16<NT>(c.wp[j >> 1] + (int64_t)(2 * (kb + 2) + (j & 1)) * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* xb = lds + (kb % XB) * kXSz;
@@ -203,7 +203,7 @@ SGLK_DEV void run(const I8GemmParams& p, unsigned char* lds, const Ctx& c) {
     }
 }
 
-template <int MODE, bool ODD, int NW = 8, int XD = 1>
+template <int MODE, bool ODD, int NW = 8, int XD = 1, bool NT = false>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_i8_mid_kernel(const I8GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_i8_mid_kernel(const I8GemmPar
     const unsigned char* wexp = p.w + (int64_t)c.e * p.w_bytes;
     c.wp[0] = wexp + ((int64_t)(c.row0[0] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
     c.wp[1] = wexp + ((int64_t)(c.row0[1] >> 4) * ctiles + 2 * c.kb0) * 1024 + lane * 16;
-    if (c.rows <= 64) run<MODE, 4, ODD, NW, XD>(p, lds, c);
-    else run<MODE, 8, ODD, NW>(p, lds, c);
+    if (c.rows <= 64) run<MODE, 4, ODD, NW, XD, NT>(p, lds, c);
+    else run<MODE, 8, ODD, NW, 1, NT>(p, lds, c);
 }
 
 // out[r][c] = cast((x_scale[r] * (float)(sum over ranges of the int32 partials)) * w_scale[c] + bias[c]): the integer sum is
@@ -380,7 +380,11 @@ int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStrea
     if (blocks == 0) return SGLK_OK;
     const bool odd = (kblocks & 1) != 0;
     const size_t lds = gimid::kLds;
-#define I8MID(MD, OD) hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p)
+#define I8MID(MD, OD)                                                                                                            \
+    {                                                                                                                            \
+        if (p.w_nt) hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MD, OD, 8, 1, true>), dim3((unsigned)blocks), dim3(512), lds, stream, p);  \
+        else hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MD, OD, 8, 1, false>), dim3((unsigned)blocks), dim3(512), lds, stream, p);        \
+    }
     if (mode == MODE_GATE_UP) {
         // decode-size launches: four-wave workgroups up to half the CUs, activations three K blocks ahead up to two rounds of the
         // chip (policy and knobs of moe_gemm_fp8w_mid.hip)
@@ -399,10 +403,11 @@ int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStrea
         else if (nw == 4 && far) I8MIDN(false, 4, 3);
         else if (nw == 4) I8MIDN(false, 4, 1);
         else if (far) I8MIDN(false, 8, 3);
-        else if (odd) I8MID(MODE_GATE_UP, true);
-        else I8MID(MODE_GATE_UP, false);
+        else if (odd) I8MID(MODE_GATE_UP, true)
+        else I8MID(MODE_GATE_UP, false)
 #undef I8MIDN
-    } else { if (odd) I8MID(MODE_DOWN, true); else I8MID(MODE_DOWN, false); }
+    } else if (odd) I8MID(MODE_DOWN, true)
+    else I8MID(MODE_DOWN, false)
 #undef I8MID
     SGLK_CHECK_LAUNCH("gemm_i8_mid");
     return SGLK_OK;

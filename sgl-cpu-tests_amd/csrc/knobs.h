@@ -27,6 +27,7 @@ struct Knobs {
     int max_wgs = 0;             // SGLK_MAX_WGS: cap on the persistent launches' workgroups (tests: forces many tiles per
                                  //               workgroup on small problems); 0 = one per CU
     int dec_nt = -1;             // SGLK_DEC_NT: 1 / 0 = decode_attention's cache rows are read with / without the non-temporal policy (-1 = on)
+    int w_nt = -1;               // SGLK_W_NT: 1 / 0 = decode-size MoE kernels read the expert weights non-temporal / not (-1 = from 32 routed rows on)
     int dec_fold = -1;           // SGLK_DEC_FOLD: 0 = decode_attention's cache write always as its own launch (-1 = folded when small)
     int dec_splits = 0;          // SGLK_DEC_SPLITS: KV splits decode_attention uses (0 = one round of workgroups, -1 = all the scratch has)
     int attn_nw = 0;             // SGLK_ATTN_NW: waves per extend-attention workgroup (4 / 8); 0 = by launch size

@@ -65,7 +65,7 @@ struct TileCtx {
 // decode-size tile has (MT = 2): there a K block is a few MFMAs, and with the activations only one block ahead every one of the
 // reduction's 56 blocks (K = 7168) waited out a global -> LDS round trip (0.9 us per block, 51 us per tile, whatever the ring depth
 // of the weights or the number of workgroups)
-template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1>
+template <int MODE, int MT, bool ODD, int NW = 8, int XD = 1, bool NT = false>
 SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
     static_assert(NW == 8 || MODE == MODE_GATE_UP, "narrow workgroups exist for GATE_UP only");
     // (ODD with XD = 3: a reduction of exactly three blocks -- expert width 384 in DOWN -- all of whose activations are requested up front)
@@ -85,7 +85,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
     u32x4 ring[2 * PB];
 #pragma unroll
     for (int i = 0; i < 2 * PB; ++i)
-        ring[i] = *reinterpret_cast<const u32x4*>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
+        ring[i] = ld_stream16<NT>(c.wp[(i % PB) >> 1] + (int64_t)(2 * (i / PB) + (i & 1)) * 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -138,7 +138,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
         }
         if (refill) {
 #pragma unroll
-            for (int j = 0; j < PB; ++j) ring[half * PB + j] = *reinterpret_cast<const u32x4*>(piece_ptr(kb + 2, j));
+            for (int j = 0; j < PB; ++j) ring[half * PB + j] = ld_stream16<NT>(piece_ptr(kb + 2, j));
         }
         __builtin_amdgcn_sched_barrier(0);
         float sc[TPW];
@@ -267,7 +267,7 @@ SGLK_DEV void run(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) 
 // DOWN over TWO neighbouring column tiles (2 x 128 output columns) of one m-tile per workgroup, even block counts: the weight
 // ring runs straight from the first tile's last K blocks into the second tile's first ones, so the pair pays ONE prologue and
 // one ring fill (a DOWN tile at N = 768 is only six blocks long); the activations are simply streamed through LDS twice.
-template <int MT>
+template <int MT, bool NT>
 SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCtx& c) {
     int my_slot = -1;
     float my_tw = 0.f;
@@ -280,7 +280,7 @@ SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCt
     };
     u32x4 ring[4];   // slot = (block & 1) * 2 + k half
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ring[i] = *reinterpret_cast<const u32x4*>(wptr(i >> 1) + (i & 1) * 1024);
+    for (int i = 0; i < 4; ++i) ring[i] = ld_stream16<NT>(wptr(i >> 1) + (i & 1) * 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -317,8 +317,8 @@ SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCt
         }
         if (refill) {
             const unsigned char* nx = wptr(vb + 2);
-            ring[half * 2] = *reinterpret_cast<const u32x4*>(nx);
-            ring[half * 2 + 1] = *reinterpret_cast<const u32x4*>(nx + 1024);
+            ring[half * 2] = ld_stream16<NT>(nx);
+            ring[half * 2 + 1] = ld_stream16<NT>(nx + 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float sc = c.sc[tile * kMaxKB + kb];
@@ -384,7 +384,7 @@ SGLK_DEV void run_down2(const MoeGemmParams& p, unsigned char* lds, const TileCt
     store(1);
 }
 
-template <int MODE, bool ODD, int NW = 8, int XD = 1>
+template <int MODE, bool ODD, int NW = 8, int XD = 1, bool NT = false>
 __global__ __launch_bounds__(NW * 64, MODE == MODE_GATE_UP ? 2 : 4) void moe_gemm_fp8w_mid_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -443,12 +443,13 @@ __global__ __launch_bounds__(NW * 64, MODE == MODE_GATE_UP ? 2 : 4) void moe_gem
     c.sc = sc;
 
     const int mt = (c.rows + 15) >> 4;
-    if (mt <= 2) run<MODE, 2, ODD, NW, XD>(p, lds, c);
-    else if (mt <= 4) run<MODE, 4, ODD, NW>(p, lds, c);
-    else run<MODE, 6, ODD, NW>(p, lds, c);
+    if (mt <= 2) run<MODE, 2, ODD, NW, XD, NT>(p, lds, c);
+    else if (mt <= 4) run<MODE, 4, ODD, NW, 1, NT>(p, lds, c);
+    else run<MODE, 6, ODD, NW, 1, NT>(p, lds, c);
 }
 
 // DOWN, two column tiles per workgroup (p.n_tiles = output columns / 256)
+template <bool NT>
 __global__ __launch_bounds__(512, 4) void moe_gemm_fp8w_mid_down2_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
@@ -483,9 +484,9 @@ __global__ __launch_bounds__(512, 4) void moe_gemm_fp8w_mid_down2_kernel(const M
     }
     c.sc = sc;
     const int mt = (c.rows + 15) >> 4;
-    if (mt <= 2) run_down2<2>(p, lds, c);
-    else if (mt <= 4) run_down2<4>(p, lds, c);
-    else run_down2<6>(p, lds, c);
+    if (mt <= 2) run_down2<2, NT>(p, lds, c);
+    else if (mt <= 4) run_down2<4, NT>(p, lds, c);
+    else run_down2<6, NT>(p, lds, c);
 }
 
 }  // namespace gmid
@@ -496,8 +497,13 @@ int launch_moe_gemm_fp8w_mid_down2(const MoeGemmParams& p, int max_mtiles, hipSt
     if (p.C % 256 != 0 || kblocks < 2 || kblocks > gmid::kMaxKB) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_mid_down2: reduction length %d", p.C);
     const int64_t blocks = (int64_t)max_mtiles * p.n_tiles;
     if (blocks == 0) return SGLK_OK;
-    SGLK_ENSURE_DYN_LDS(gmid::moe_gemm_fp8w_mid_down2_kernel, gmid::kLds, "moe_gemm_fp8w_mid_down2");
-    hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_down2_kernel, dim3((unsigned)blocks), dim3(512), gmid::kLds, stream, p);
+    if (p.w_nt) {
+        SGLK_ENSURE_DYN_LDS(gmid::moe_gemm_fp8w_mid_down2_kernel<true>, gmid::kLds, "moe_gemm_fp8w_mid_down2");
+        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_down2_kernel<true>, dim3((unsigned)blocks), dim3(512), gmid::kLds, stream, p);
+    } else {
+        SGLK_ENSURE_DYN_LDS(gmid::moe_gemm_fp8w_mid_down2_kernel<false>, gmid::kLds, "moe_gemm_fp8w_mid_down2");
+        hipLaunchKernelGGL(gmid::moe_gemm_fp8w_mid_down2_kernel<false>, dim3((unsigned)blocks), dim3(512), gmid::kLds, stream, p);
+    }
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid_down2");
     return SGLK_OK;
 }
@@ -512,10 +518,14 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
     if ((nsplit > 1 && !p.partial) || (p.partial && (p.out_cols <= 0 || p.split_rows <= 0)))
         SGLK_FAIL(SGLK_ERR_INVALID, "moe_gemm_fp8w_mid: split-K without a partial buffer");
     const size_t lds = gmid::kLds;
+#define MID_LAUNCH3(MD, OD, XDV, NTV)                                                                              \
+    {                                                                                                              \
+        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MD, OD, 8, XDV, NTV>), lds, "moe_gemm_fp8w_mid");      \
+        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MD, OD, 8, XDV, NTV>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
+    }
 #define MID_LAUNCH2(MD, OD)                                                                                        \
     {                                                                                                              \
-        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MD, OD>), lds, "moe_gemm_fp8w_mid");                   \
-        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MD, OD>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
+        if (MD != MODE_PLAIN && p.w_nt) MID_LAUNCH3(MD, OD, 1, (MD != MODE_PLAIN)) else MID_LAUNCH3(MD, OD, 1, false)  \
     }
 #define MID_LAUNCH(MD)                                                                                             \
     {                                                                                                              \
@@ -549,12 +559,12 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
 #undef MID_NARROW
     } else if (mode == MODE_GATE_UP) MID_LAUNCH(MODE_GATE_UP)
     else if (mode == MODE_DOWN && kblocks == 3 && !knobs().no_mid_narrow) {   // short tiles request their three K blocks of activations up front
-        SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN, true, 8, 3>), lds, "moe_gemm_fp8w_mid");
-        hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MODE_DOWN, true, 8, 3>), dim3((unsigned)blocks), dim3(512), lds, stream, p);
+        if (p.w_nt) MID_LAUNCH3(MODE_DOWN, true, 3, true) else MID_LAUNCH3(MODE_DOWN, true, 3, false)
     } else if (mode == MODE_DOWN) MID_LAUNCH(MODE_DOWN)
     else MID_LAUNCH(MODE_PLAIN)
 #undef MID_LAUNCH
 #undef MID_LAUNCH2
+#undef MID_LAUNCH3
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_mid");
     return SGLK_OK;
 }

@@ -34,7 +34,7 @@ SGLK_DEV bf16x8 cvt8(unsigned lo, unsigned hi) {
     return r;
 }
 
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];   // [32 tokens][C] bf16, swizzled
 
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeG
 
     u32x4 ring[kDepth];   // npieces >= kDepth: C >= 256
 #pragma unroll
-    for (int i = 0; i < kDepth; ++i) ring[i] = *reinterpret_cast<const u32x4*>(piece_ptr(i));
+    for (int i = 0; i < kDepth; ++i) ring[i] = ld_stream16<NT>(piece_ptr(i));
 
     // ---- activations of the token tile -> LDS, whole reduction length -----------------------------------------------
     {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void moe_gemm_fp8w_stream_kernel(const MoeG
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
             const u32x4 raw = ring[j];
-            ring[j] = *reinterpret_cast<const u32x4*>(piece_ptr(base + j + kDepth));
+            ring[j] = ld_stream16<NT>(piece_ptr(base + j + kDepth));
             consume(raw, base + j);
         }
     }
@@ -190,13 +190,17 @@ int launch_moe_gemm_fp8w_stream(int mode, const MoeGemmParams& p, int max_mtiles
     if (blocks == 0) return SGLK_OK;
     const size_t lds = (size_t)kStreamTileM * p.C * 2;
     if (lds > 150 * 1024) SGLK_FAIL(SGLK_ERR_SHAPE, "moe_gemm_fp8w_stream: reduction length %d too long for the LDS tile", p.C);
-    if (mode == MODE_GATE_UP) {
-        SGLK_ENSURE_DYN_LDS(gstream::moe_gemm_fp8w_stream_kernel<MODE_GATE_UP>, 150 * 1024, "moe_gemm_fp8w_stream");
-        hipLaunchKernelGGL(gstream::moe_gemm_fp8w_stream_kernel<MODE_GATE_UP>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
-    } else {
-        SGLK_ENSURE_DYN_LDS(gstream::moe_gemm_fp8w_stream_kernel<MODE_DOWN>, 150 * 1024, "moe_gemm_fp8w_stream");
-        hipLaunchKernelGGL(gstream::moe_gemm_fp8w_stream_kernel<MODE_DOWN>, dim3((unsigned)blocks), dim3(512), lds, stream, p);
+#define STREAM_LAUNCH(MD, NTV)                                                                                     \
+    {                                                                                                              \
+        SGLK_ENSURE_DYN_LDS((gstream::moe_gemm_fp8w_stream_kernel<MD, NTV>), 150 * 1024, "moe_gemm_fp8w_stream");  \
+        hipLaunchKernelGGL((gstream::moe_gemm_fp8w_stream_kernel<MD, NTV>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
     }
+    if (mode == MODE_GATE_UP) {
+        if (p.w_nt) STREAM_LAUNCH(MODE_GATE_UP, true) else STREAM_LAUNCH(MODE_GATE_UP, false)
+    } else {
+        if (p.w_nt) STREAM_LAUNCH(MODE_DOWN, true) else STREAM_LAUNCH(MODE_DOWN, false)
+    }
+#undef STREAM_LAUNCH
     SGLK_CHECK_LAUNCH("moe_gemm_fp8w_stream");
     return SGLK_OK;
 }

@@ -38,6 +38,7 @@ struct MoeGemmParams {
     // partial [range][row][out_cols] reduced by launch_splitk_reduce; ksplit <= 1: whole reduction, bf16 out (+ bias)
     int ksplit, split_kblocks, split_rows, out_cols;
     float* partial;
+    int w_nt;               // decode-size kernels: read the weights with the non-temporal policy (sglk_common.h, ld_stream16)
     // PLAIN on the 256-row kernel with split-K (dense GEMMs whose tiles would not fill the chip): the tile table's "expert" is
     // the K range; C = the range's length, c_full = the whole reduction length (row stride of the packed weight / scale table),
     // w_expert_stride = bytes of one range inside a row tile, w_bytes_total = extent of the weight for the buffer descriptor
@@ -133,6 +134,7 @@ struct I8GemmParams {
     // PLAIN on the weight-streaming kernel (decode-size dense W8A8, gemm_i8_mid.hip): N output columns, K ranges of
     // split_kblocks 128-wide blocks with exact int32 partials [range][M][N] (ksplit <= 1: whole reduction, direct output)
     int N, ksplit, split_kblocks;
+    int w_nt;               // MoE launches of the mid kernel: non-temporal weight reads (ld_stream16)
     int32_t* partial_i32;
     int out_type;             // PLAIN: SGLK_OUT_* of `out`
     // PLAIN on the 256-row kernel: out += addend[row][col] * addend_scale in fp32 before the bf16 rounding (shared expert), or null

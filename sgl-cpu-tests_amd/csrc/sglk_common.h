@@ -73,6 +73,15 @@ SGLK_DEV unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// 16 bytes of a weight stream.  NT: the non-temporal policy, for weights that one workgroup reads once per call (MoE experts at decode
+// sizes): same-box A/B of fused_experts fp8, replayed and with rotating weight copies alike (profiles/r03_ab_nt_weights.txt): 7-10 % less
+// time from 16 tokens on, nothing at 4, 13 % MORE at one token -- the launcher decides (MoeGemmParams::w_nt).
+template <bool NT>
+SGLK_DEV u32x4 ld_stream16(const void* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+}
+
 // g * sigmoid(g) with the hardware exp2 / rcp (1 ulp each): far inside the bf16 rounding of the result
 SGLK_DEV float silu_f32(float g) {
     return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896340736f));

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: per-stage times (library HIP events) of one fused_experts configuration.
-    python tools/stage_probe.py [fp8|int8] [M]"""
+    python tools/stage_probe.py [fp8|int8] [M]
+SGLK_PROBE_SHAPE=K,N,E,topk picks the shape; SGLK_PROBE_ROTATE=n calls n clones of the weights in turn (a small batch re-reads the same
+experts from the Infinity Cache otherwise)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sgl-cpu-tests_amd"))
@@ -24,6 +26,16 @@ else:
     w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
     s1 = torch.randn(E, 2 * N // 128, K // 128, device="cuda", generator=g) * 1e-3; s2 = torch.randn(E, K // 128, N // 128, device="cuda", generator=g) * 1e-3
     f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, True, s1, s2, [128, 128], None, None, True)
+ROT = int(os.environ.get("SGLK_PROBE_ROTATE", "1"))
+if ROT > 1:
+    sets = [(w1, w2)] + [(w1.clone(), w2.clone()) for _ in range(ROT - 1)]
+    state = {"i": 0}
+    def f():
+        state["i"] += 1
+        c1, c2 = sets[state["i"] % ROT]
+        if kind == "int8":
+            return ops.fused_experts_cpu(a, c1, c2, tw, ids, False, True, False, s1, s2, None, None, None, True)
+        return ops.fused_experts_cpu(a, c1, c2, tw, ids, False, False, True, s1, s2, [128, 128], None, None, True)
 L = _lib.lib()
 for _ in range(5): f()
 torch.cuda.synchronize()
@@ -39,4 +51,4 @@ e0.record()
 for _ in range(20): f()
 e1.record(); torch.cuda.synchronize()
 print(kind, "M", M, "K,N,E,topk", (K, N, E, topk), {n: round(float(ms[i]), 4) for i, n in enumerate(_lib.STAGE_NAMES)}, "sum", round(sum(ms), 4),
-      "call (events around 20 calls)", round(e0.elapsed_time(e1) / 20, 4), "path", hex(_ops.last_path))
+      "call (events around 20 calls)", round(e0.elapsed_time(e1) / 20, 4), "path", hex(_ops.last_path), "rotate", ROT)
