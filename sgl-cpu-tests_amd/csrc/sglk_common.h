@@ -75,7 +75,8 @@ SGLK_DEV unsigned pack_bf16x2(float lo, float hi) {
 
 // 16 bytes of a weight stream.  NT: the non-temporal policy, for weights that one workgroup reads once per call (MoE experts at decode
 // sizes): same-box A/B of fused_experts fp8, replayed and with rotating weight copies alike (profiles/r03_ab_nt_weights.txt): 7-10 % less
-// time from 16 tokens on, nothing at 4, 13 % MORE at one token -- the launcher decides (MoeGemmParams::w_nt).
+// time from 16 tokens on, nothing at 4, 13 % MORE at one token -- the launcher decides (MoeGemmParams::w_nt).  The bf16 mid kernel's
+// dword loads of VNNI-packed weights got 7-12 % SLOWER with it (same file): that kernel keeps the default policy.
 template <bool NT>
 SGLK_DEV u32x4 ld_stream16(const void* p) {
     if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 KIND=${1:-fp8}
 for rot in 1 3; do
 for shape in 2048,768,128,8 7168,384,256,8; do
-for m in 1 4 8 16 64 256 1024; do
+for m in ${NT_AB_M:-1 4 8 16 64 256 1024}; do
     r=$rot; [ $rot = 3 ] && [ $shape = 7168,384,256,8 ] && r=2
     for nt in 0 1 auto; do
         v=$nt; [ $nt = auto ] && v=

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: per-stage times (library HIP events) of one fused_experts configuration.
-    python tools/stage_probe.py [fp8|int8] [M]
+    python tools/stage_probe.py [fp8|int8|bf16] [M]
 SGLK_PROBE_SHAPE=K,N,E,topk picks the shape; SGLK_PROBE_ROTATE=n calls n clones of the weights in turn (a small batch re-reads the same
 experts from the Infinity Cache otherwise)."""
 import ctypes, os, sys
@@ -21,6 +21,11 @@ if kind == "int8":
     w2 = ops.convert_weight_packed(torch.randint(-127, 128, (E, K, N), device="cuda", generator=g, dtype=torch.int8))
     s1 = torch.rand(E, 2 * N, device="cuda", generator=g) * 1e-3; s2 = torch.rand(E, K, device="cuda", generator=g) * 1e-3
     f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, True, False, s1, s2, None, None, None, True)
+elif kind == "bf16":
+    w1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) / K ** 0.5).bfloat16())
+    w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) / N ** 0.5).bfloat16())
+    s1 = s2 = None
+    f = lambda: ops.fused_experts_cpu(a, w1, w2, tw, ids, False, False, False, None, None, None, None, None, True)
 else:
     w1 = ops.convert_weight_packed((torch.randn(E, 2 * N, K, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
     w2 = ops.convert_weight_packed((torch.randn(E, K, N, device="cuda", generator=g) * 400).clamp(-400, 400).to(torch.float8_e4m3fn))
@@ -35,6 +40,8 @@ if ROT > 1:
         c1, c2 = sets[state["i"] % ROT]
         if kind == "int8":
             return ops.fused_experts_cpu(a, c1, c2, tw, ids, False, True, False, s1, s2, None, None, None, True)
+        if kind == "bf16":
+            return ops.fused_experts_cpu(a, c1, c2, tw, ids, False, False, False, None, None, None, None, None, True)
         return ops.fused_experts_cpu(a, c1, c2, tw, ids, False, False, True, s1, s2, [128, 128], None, None, True)
 L = _lib.lib()
 for _ in range(5): f()
