@@ -523,6 +523,8 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
         SGLK_ENSURE_DYN_LDS((gmid::moe_gemm_fp8w_mid_kernel<MD, OD, 8, XDV, NTV>), lds, "moe_gemm_fp8w_mid");      \
         hipLaunchKernelGGL((gmid::moe_gemm_fp8w_mid_kernel<MD, OD, 8, XDV, NTV>), dim3((unsigned)blocks), dim3(512), lds, stream, p); \
     }
+// dense (PLAIN) launches keep the default policy: non-temporal reads made fp8_scaled_mm at 1 ... 96 rows 0-10 % slower on weights of
+// 8-25 MB, replayed or rotating (tools/dense_probe.py, profiles/r03_ab_nt_weights.txt)
 #define MID_LAUNCH2(MD, OD)                                                                                        \
     {                                                                                                              \
         if (MD != MODE_PLAIN && p.w_nt) MID_LAUNCH3(MD, OD, 1, (MD != MODE_PLAIN)) else MID_LAUNCH3(MD, OD, 1, false)  \
