@@ -1000,6 +1000,11 @@ struct DecodeParams {
     int HQ, HKV, splits, logit_splits, v_alias;   // splits used / depth of the caller's scratch
     float sm_scale, logit_cap;
     int nt;                 // cache rows are read non-temporal
+    // direct: one split per request -> the kernel rounds and stores the output itself and no merge is launched (what the merge of ONE
+    // split computes is bf16(1.0 * v / 1.0): the same bits)
+    unsigned short* o;
+    int64_t o_s0, o_s1;
+    int direct;
     // fold_write: the new token's rows (k_buffer[loc[b]] = key[b], v_buffer[loc[b]] = value[b]) are written by the attention
     // kernel itself -- EVERY workgroup writes the rows of its kv head for all B requests before it requests anything, so whatever
     // cache row a page table names (another request's new row included) holds the new bytes by the time it is read
@@ -1250,6 +1255,18 @@ __global__ __launch_bounds__(256 * KH, 1) void decode_attention_kernel(const Dec
     float* dst = p.logits + (((int64_t)b * p.HQ + h) * p.logit_splits + split) * (DV + 1);
     const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
     const int g4 = (lane >> 4) * 4;
+    if (p.direct) {
+        unsigned short* orow = p.o + (int64_t)b * p.o_s0 + (int64_t)h * p.o_s1 + dsl * DVW + g4;
+#pragma unroll
+        for (int t = 0; t < DVW / 16; ++t) {
+            const f32x4 v = core.o[0][t] * inv;
+            uint2 w;
+            w.x = pack_bf16x2(v[0], v[1]);
+            w.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(orow + t * 16) = w;
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < DVW / 16; ++t) {
         const f32x4 v = core.o[0][t] * inv;
@@ -1533,6 +1550,8 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
     p.key = (const unsigned short*)a->key; p.value = (const unsigned short*)a->value; p.loc = a->loc; p.loc_is64 = a->loc_is64;
     p.key_s0 = a->key_stride[0]; p.key_s1 = a->key_stride[1]; p.val_s0 = a->value_stride[0]; p.val_s1 = a->value_stride[1];
     p.B = a->B; p.fold_write = fold ? 1 : 0;
+    p.o = (unsigned short*)a->o; p.o_s0 = a->o_stride[0]; p.o_s1 = a->o_stride[1];
+    p.direct = (eff == 1 && a->o_stride[0] % 4 == 0 && a->o_stride[1] % 4 == 0 && ((uintptr_t)a->o % 8) == 0) ? 1 : 0;
     const dim3 grid((unsigned)a->B, (unsigned)a->HKV, (unsigned)eff);
     const int group = a->HQ / a->HKV;
 #define DEC_LAUNCH(DD, DDV, AL, ND)                                                                                \
@@ -1555,6 +1574,7 @@ extern "C" int sglk_decode_attention(const sglk_decode_attention_args* a, void* 
             else DEC_LAUNCH(DD, DDV, false, 1)                                                                     \
         }                                                                                                          \
         SGLK_CHECK_LAUNCH("decode_attention");                                                                     \
+        if (p.direct) return SGLK_OK;                                                                              \
         hipLaunchKernelGGL(decode_merge_kernel, dim3((unsigned)a->B, (unsigned)a->HQ), dim3(256), 0, s, a->attn_logits,    \
                            (unsigned short*)a->o, a->o_stride[0], a->o_stride[1], a->HQ, eff, a->splits, a->DV);   \
         SGLK_CHECK_LAUNCH("decode_attention(merge)");                                                              \

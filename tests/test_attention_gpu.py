@@ -173,6 +173,46 @@ def test_decode_attention_cache_write_inside_the_kernel(ops, knob, shape):
     assert err < 6e-3, f"relative RMS error {err:.2e}: a stale cache row would be far off"
 
 
+@pytest.mark.parametrize("shape", [(5, 22, 1, 576, 512, True), (9, 32, 4, 128, 128, False)], ids=["mla", "gqa"])
+def test_decode_attention_one_split_writes_the_output_itself(ops, knob, shape):
+    """With one split per request (large batches; forced here by SGLK_DEC_SPLITS=1) the attention kernel stores the rounded output and
+    no merge kernel runs.  Same bits as the merge of one split: checked against the same call into an output whose rows are not 8-byte
+    aligned (that one goes through the merge), and against the oracle."""
+    B, HQ, HKV, D, DV, alias = shape
+    L = 333
+    g = torch.Generator().manual_seed(5)
+    total = B * L
+    q = torch.randn(B, HQ, D, generator=g).bfloat16()
+    kb = torch.randn(total, HKV, D, generator=g).bfloat16()
+    vb = None if alias else torch.randn(total, HKV, DV, generator=g).bfloat16()
+    key = torch.randn(B, HKV, D, generator=g).bfloat16()
+    value = None if alias else torch.randn(B, HKV, DV, generator=g).bfloat16()
+    rtt = torch.randperm(total, generator=g).view(B, L)
+    lens = torch.tensor([L - 11 * b for b in range(B)])
+    loc = torch.stack([rtt[b, lens[b] - 1] for b in range(B)])
+    scale = 1.0 / D ** 0.5
+    knob(SGLK_DEC_SPLITS=1)
+
+    def run(o):
+        kbd = kb.cuda()
+        vbd = kbd.narrow(2, 0, DV) if alias else vb.cuda()
+        logits = torch.zeros(B, HQ, 8, DV + 1, dtype=torch.float32, device="cuda")
+        kd = key.cuda()
+        ops.decode_attention_cpu(q.cuda(), kbd, vbd, o, kd, kd.narrow(2, 0, DV) if alias else value.cuda(), loc.cuda(), logits,
+                                 rtt.cuda(), torch.arange(B).cuda(), lens.cuda(), scale, 0.0)
+        return o.cpu(), logits.cpu()
+
+    direct, lg_direct = run(torch.zeros(B, HQ, DV, dtype=torch.bfloat16, device="cuda"))
+    wide = torch.zeros(B, HQ, DV + 2, dtype=torch.bfloat16, device="cuda")
+    merged, lg_merged = run(wide[:, :, 1:DV + 1])
+    assert lg_direct.abs().sum() == 0 and lg_merged.abs().sum() > 0, "the direct form must not touch attn_logits; the other one must"
+    assert torch.equal(direct, merged)
+    kb2 = kb.clone()
+    vb2 = kb2.narrow(2, 0, DV) if alias else vb.clone()
+    ref = oattn.decode_attention(q, kb2, vb2, key, key.narrow(2, 0, DV) if alias else value, loc, rtt, torch.arange(B), lens, scale)
+    assert (direct.float() - ref).norm() / ref.norm() < 6e-3
+
+
 # ---- BASELINE.json config 3 at its own sizes (seqlen <= 8k): /root/reference/bench_extend.py:107-112, test_mla.py:178-186 ----
 @pytest.mark.parametrize("case", recipes.EXTEND_BIG_CASES, ids=lambda c: c[0])
 def test_extend_attention_bench_sizes(ops, case):
