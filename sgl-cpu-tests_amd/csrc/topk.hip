@@ -26,24 +26,56 @@ constexpr int kRouteAlignMaxTokens = 16;
 constexpr int kRouteAlignMaxSlots = 1024;
 constexpr int kPerLane = kTopkMaxE / 64;
 
+// Cross-lane reductions on the DPP path of the vector ALU, not through ds_bpermute: four steps inside the rows of 16 lanes
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: after them every lane of a row holds the row's result), then the four rows'
+// results are read as scalars.  A routed token needs ~25 of these one after the other; as bpermute chains (a trip through the LDS
+// unit per step, six steps each) they were most of the kernel's 52 us at 16384 tokens.
+template <int CTRL>
+SGLK_DEV float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+SGLK_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+SGLK_DEV float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
 SGLK_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f<kDppMirror>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 SGLK_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    v += dpp_f<kDppHalfMirror>(v);
+    v += dpp_f<kDppMirror>(v);
+    return ((lane_f(v, 0) + lane_f(v, 16)) + lane_f(v, 32)) + lane_f(v, 48);
 }
-// arg-max over the wave of (value, index): larger value wins, ties -> lower index
+// arg-max over the wave of (value, index): larger value wins, ties -> lower index.  (value desc, index asc) is a total order on
+// NaN-free input, so the winner does not depend on the shape of the reduction tree.  The result is wave-uniform.
+template <int CTRL>
+SGLK_DEV void argmax_step(float& v, int& i) {
+    const float ov = dpp_f<CTRL>(v);
+    const int oi = dpp_i<CTRL>(i);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 SGLK_DEV void wave_argmax(float& v, int& i) {
+    argmax_step<kDppXor1>(v, i);
+    argmax_step<kDppXor2>(v, i);
+    argmax_step<kDppHalfMirror>(v, i);
+    argmax_step<kDppMirror>(v, i);
+    float bv = lane_f(v, 0);
+    int bi = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o);
-        const int oi = __shfl_xor(i, o);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = lane_f(v, r);
+        const int oi = __builtin_amdgcn_readlane(i, r);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    v = bv;
+    i = bi;
 }
 
 template <int GT>   // gating element type: 0 bf16, 1 f16, 2 f32
@@ -101,8 +133,10 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     // ---- group scores, one lane per group (G <= 64) ------------------------------------------------------------------
+    // (one group -- plain top-k routing, Qwen3 -- is selected whatever its score: nothing to rank.  The general path below had lane 0
+    // walk all E experts through LDS, one dependent read after the other.)
     float gs = -INFINITY;
-    if (lane < G) {
+    if (G > 1 && lane < G) {
         float a = -INFINITY, b = -INFINITY;   // two largest of the group
         for (int i = 0; i < per_group; ++i) {
             const float v = choice_l[lane * per_group + i];
@@ -111,8 +145,8 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
         gs = BIASED ? a + b : a;
     }
     // ---- the topk_group best groups -> bitmask ----------------------------------------------------------------------------
-    unsigned long long gmask = 0ull;
-    for (int r = 0; r < topk_group; ++r) {
+    unsigned long long gmask = G == 1 ? 1ull : 0ull;
+    for (int r = 0; G > 1 && r < topk_group; ++r) {
         float v = (lane < G && !((gmask >> lane) & 1ull)) ? gs : -INFINITY;
         int i = lane;
         // -inf group scores (NaN-free inputs only produce them for padding lanes) still need a deterministic pick
@@ -156,7 +190,7 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
             for (int o = 32; o > 0; o >>= 1) { const int oc = __shfl_xor(cand, o); cand = oc < cand ? oc : cand; }
             i = cand < E ? cand : 0;
         }
-        // owner lane retires the pick and supplies its (unbiased) score
+        // owner lane retires the pick and supplies its (unbiased) score; i is wave-uniform: the score is read from the owner's lane
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
             if (j * 64 + lane == i) {
@@ -166,7 +200,7 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
                 choice[j] = INFINITY;   // taken
             }
         }
-        w_sel = wave_sum(w_sel);
+        w_sel = lane_f(w_sel, __builtin_amdgcn_readfirstlane(i) & 63);
         wsum += w_sel;
         if (lane == r) { my_w = w_sel; my_id = i; }
     }
