@@ -32,25 +32,44 @@ struct RowSrc {                 // a [rows][n] bf16 matrix, or the fp32 split-K 
     const unsigned short* dense;
     int64_t dense_stride;
 };
-SGLK_DEV float row_val(const RowSrc& s, int64_t r, int c) {
+// Two elements (row, column) at a time (c1 < 0: one).  Ascending ranges, as the reduce kernel sums them.  All the loads of a batch of BATCH
+// ranges -- of BOTH columns -- are in flight together: a range past the end re-reads the last one and is not added.  (Eight per batch,
+// a serial tail, and one column after the other made these two kernels a chain of five to ten memory round trips: 7.4 and 5.9 us at
+// one token, more than any of the three projections between them.)
+template <int BATCH>
+SGLK_DEV void row_val2_b(const RowSrc& s, int64_t r0, int c0, int64_t r1, int c1, float& v0, float& v1) {
+    const bool two = c1 >= 0;
     if (s.partial) {
-        // ascending ranges, as the reduce kernel sums them; eight loads in flight per batch (a serial load-add chain over 28
-        // ranges made this kernel slower than the launches it replaces)
-        const float* p = s.partial + r * s.n + c;
+        const float* p0 = s.partial + r0 * s.n + c0;
+        const float* p1 = two ? s.partial + r1 * s.n + c1 : p0;
         const int64_t step = s.rows * s.n;
-        float v = 0.f;
-        int k = 0;
-        for (; k + 8 <= s.ks; k += 8) {
-            float t[8];
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < s.ks; k += BATCH) {
+            float t0[BATCH], t1[BATCH];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = p[(int64_t)(k + j) * step];
+            for (int j = 0; j < BATCH; ++j) {
+                const int kk = k + j < s.ks ? k + j : s.ks - 1;
+                t0[j] = p0[(int64_t)kk * step];
+                t1[j] = p1[(int64_t)kk * step];
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j];
+            for (int j = 0; j < BATCH; ++j) {
+                if (k + j < s.ks) {
+                    a0 += t0[j];
+                    a1 += t1[j];
+                }
+            }
         }
-        for (; k < s.ks; ++k) v += p[(int64_t)k * step];
-        return bf16_bits_to_f32(f32_to_bf16_bits(v));                                          // the projection's bf16 output
+        v0 = bf16_bits_to_f32(f32_to_bf16_bits(a0));                                          // the projection's bf16 output
+        v1 = bf16_bits_to_f32(f32_to_bf16_bits(a1));
+        return;
     }
-    return bf16_bits_to_f32(s.dense[r * s.dense_stride + c]);
+    v0 = bf16_bits_to_f32(s.dense[r0 * s.dense_stride + c0]);
+    v1 = two ? bf16_bits_to_f32(s.dense[r1 * s.dense_stride + c1]) : 0.f;
+}
+SGLK_DEV void row_val2(const RowSrc& s, int64_t r0, int c0, int64_t r1, int c1, float& v0, float& v1) {
+    if (s.ks <= 8) row_val2_b<8>(s, r0, c0, r1, c1, v0, v1);      // few ranges (q_b): no sixteen-wide batch of mostly repeated loads
+    else row_val2_b<16>(s, r0, c0, r1, c1, v0, v1);
 }
 SGLK_DEV float block_sum_1024(float v, float* red) {
 #pragma unroll
@@ -86,10 +105,16 @@ __global__ __launch_bounds__(1024) void qkv_mid_kernel(RowSrc qa, RowSrc lat, co
     const RowSrc& src = kv ? lat : qa;
     const int width = kv ? R + rope : QL, normed = kv ? R : QL;
     float ss = 0.f;
-    for (int c = threadIdx.x; c < width; c += 1024) {
-        const float f = row_val(src, b, c);
-        rowbuf[c] = f;
-        if (c < normed) ss += f * f;
+    for (int c = threadIdx.x; c < width; c += 2048) {
+        const int c1 = c + 1024 < width ? c + 1024 : -1;
+        float f0, f1;
+        row_val2(src, b, c, b, c1, f0, f1);
+        rowbuf[c] = f0;
+        if (c < normed) ss += f0 * f0;
+        if (c1 >= 0) {
+            rowbuf[c1] = f1;
+            if (c1 < normed) ss += f1 * f1;
+        }
     }
     const float var = block_sum_1024(ss, red) / (float)normed;     // the barriers inside also publish rowbuf
     const float inv = rsqrtf(var + eps);
@@ -125,9 +150,16 @@ __global__ __launch_bounds__(256) void qkv_tail_kernel(RowSrc q2, const unsigned
     const int oc = blockIdx.y * 64 + (threadIdx.x & 63);
     const int b0 = blockIdx.z * kRows, bl = threadIdx.x >> 6;
     const int ncol = blockIdx.y == 0 ? qk : IC;        // only the rope workgroups need the pe part
-    for (int i = threadIdx.x; i < kRows * ncol; i += 256) {
-        const int r = i / ncol, c = i - r * ncol;
-        xs[r * qk + c] = (b0 + r < B) ? row_val(q2, b0 + r, h * qk + c) : 0.f;
+    for (int i = threadIdx.x; i < kRows * ncol; i += 512) {
+        const int i1 = i + 256 < kRows * ncol ? i + 256 : -1;
+        const int r0 = i / ncol, c0 = i - r0 * ncol;
+        const int r1 = i1 >= 0 ? i1 / ncol : r0, c1 = i1 >= 0 ? i1 - r1 * ncol : c0;
+        // rows past the batch read row B - 1 (valid memory) and store zeros
+        const int rr0 = b0 + r0 < B ? b0 + r0 : B - 1, rr1 = b0 + r1 < B ? b0 + r1 : B - 1;
+        float f0, f1;
+        row_val2(q2, rr0, h * qk + c0, rr1, i1 >= 0 ? h * qk + c1 : -1, f0, f1);
+        xs[r0 * qk + c0] = b0 + r0 < B ? f0 : 0.f;
+        if (i1 >= 0) xs[r1 * qk + c1] = b0 + r1 < B ? f1 : 0.f;
     }
     __syncthreads();
     if (blockIdx.y == 0 && (int)threadIdx.x < kRows * (rope / 2)) {
@@ -275,6 +307,8 @@ extern "C" int sglk_qkv_proj_with_rope(const sglk_qkv_proj_args* a, void* stream
     };
     hipStream_t s = (hipStream_t)stream;
     SplitkCapture c1{}, c2{}, c3{};
+    // (kv_a on a second stream beside q_a -- fork and join inside the call -- was built and measured: 30.5-31.1 us either way at one
+    // token in hipGraph replays, so the call stays on one stream.)
     int rc = lin(a->hidden, a->hidden_stride, a->q_a_w, a->q_a_scale, a->packed_q_a, qa, QL, hidden, w.mm, &c1);
     if (rc != SGLK_OK) return rc;
     rc = lin(a->hidden, a->hidden_stride, a->kv_a_w, a->kv_a_scale, a->packed_kv_a, latent, R + rope, hidden, w.mm2, &c2);
