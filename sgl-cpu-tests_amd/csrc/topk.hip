@@ -78,6 +78,37 @@ SGLK_DEV void wave_argmax(float& v, int& i) {
     i = bi;
 }
 
+// The picks run on ONE 64-bit key per candidate: (order-preserving image of the fp32 value) << 32 | ~index, so that the unsigned
+// maximum is "larger value first, equal values -> lower index first" and a step of the reduction is two DPP moves, one 64-bit
+// compare and two selects.  Key 0 = not a candidate (every real value, -inf included, maps above it).  The four rows are combined
+// with row_bcast15 / row_bcast31 (the wave's maximum ends up in row 3) and read from lane 63: wave-uniform.
+typedef unsigned long long u64;
+SGLK_DEV u64 topk_key(float v, int index) {
+    const unsigned b = __float_as_uint(v + 0.f);     // -0 -> +0: the two compare equal as floats and must tie here too
+    const unsigned ord = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((u64)ord << 32) | (unsigned)(~index);
+}
+SGLK_DEV int topk_key_index(u64 k) { return (int)(~(unsigned)k); }
+template <int CTRL, int ROW_MASK>
+SGLK_DEV u64 key_max_step(u64 k) {      // lanes of rows outside ROW_MASK read their own key back
+    const int lo = (int)(unsigned)k, hi = (int)(unsigned)(k >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const u64 o = ((u64)ohi << 32) | olo;
+    return o > k ? o : k;
+}
+SGLK_DEV u64 wave_max_key(u64 k) {
+    k = key_max_step<kDppXor1, 0xf>(k);
+    k = key_max_step<kDppXor2, 0xf>(k);
+    k = key_max_step<kDppHalfMirror, 0xf>(k);
+    k = key_max_step<kDppMirror, 0xf>(k);
+    k = key_max_step<0x142, 0xa>(k);     // row_bcast15: rows 1, 3 take in rows 0, 2
+    k = key_max_step<0x143, 0xc>(k);     // row_bcast31: rows 2, 3 take in rows 0 + 1
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+    return ((u64)hi << 32) | lo;
+}
+
 template <int GT>   // gating element type: 0 bf16, 1 f16, 2 f32
 SGLK_DEV float ld_gate(const void* p, int64_t idx) {
     if (GT == 2) return reinterpret_cast<const float*>(p)[idx];
@@ -147,12 +178,9 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
     // ---- the topk_group best groups -> bitmask ----------------------------------------------------------------------------
     unsigned long long gmask = G == 1 ? 1ull : 0ull;
     for (int r = 0; G > 1 && r < topk_group; ++r) {
-        float v = (lane < G && !((gmask >> lane) & 1ull)) ? gs : -INFINITY;
-        int i = lane;
-        // -inf group scores (NaN-free inputs only produce them for padding lanes) still need a deterministic pick
-        if (lane >= G || ((gmask >> lane) & 1ull)) i = 1 << 20;
-        wave_argmax(v, i);
-        if (i < G) gmask |= 1ull << i;
+        // a group whose score is -inf is still a candidate (its key is above 0); taken groups and padding lanes are not
+        const u64 k = wave_max_key((lane < G && !((gmask >> lane) & 1ull)) ? topk_key(gs, lane) : 0ull);
+        if (k != 0ull) gmask |= 1ull << topk_key_index(k);
     }
     // ---- topk experts among the selected groups --------------------------------------------------------------------------
     float masked[PL];
@@ -162,22 +190,19 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
         const bool in = e < E && ((gmask >> (e / per_group)) & 1ull);
         masked[j] = in ? choice[j] : -INFINITY;
     }
+    u64 key[PL];
+#pragma unroll
+    for (int j = 0; j < PL; ++j) key[j] = masked[j] > -INFINITY ? topk_key(masked[j], j * 64 + lane) : 0ull;   // e >= E is -inf already
     wsum = 0.f;
     my_w = 0.f;
     my_id = 0;
     for (int r = 0; r < topk; ++r) {
-        float bv = -INFINITY;
-        int bi = 1 << 20;
+        u64 kb = key[0];
 #pragma unroll
-        for (int j = 0; j < PL; ++j) {
-            const int e = j * 64 + lane;
-            // only live candidates (> -inf); equal values -> lower index
-            if (e < E && masked[j] > -INFINITY && (masked[j] > bv || (masked[j] == bv && e < bi))) { bv = masked[j]; bi = e; }
-        }
+        for (int j = 1; j < PL; ++j) kb = key[j] > kb ? key[j] : kb;
+        kb = wave_max_key(kb);
         // second chance: nothing left in the selected groups -> lowest-index expert not taken yet (weight 0 / raw score)
-        float v = bv;
-        int i = bi;
-        wave_argmax(v, i);
+        int i = kb != 0ull ? topk_key_index(kb) : (1 << 20);
         float w_sel = 0.f;
         if (i >= E) {   // all remaining candidates are -inf: take the lowest index still marked "not taken"
             int cand = 1 << 20;
@@ -197,6 +222,7 @@ SGLK_DEV void route_one_token(const void* __restrict__ gating, int64_t g_stride,
                 const bool was_selected_group = masked[j] != -INFINITY;
                 w_sel = (BIASED || was_selected_group) ? score[j] : 0.f;
                 masked[j] = -INFINITY;
+                key[j] = 0ull;
                 choice[j] = INFINITY;   // taken
             }
         }
