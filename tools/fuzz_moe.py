@@ -23,6 +23,7 @@ KIND = os.environ.get("FUZZ_KIND", "fp8")
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20261004)
 fails, paths = 0, {}
 TIMES = os.environ.get("FUZZ_TIME", "0") == "1"
+ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))
 slow = []
 
 
@@ -52,17 +53,20 @@ for it in range(iters):
     packed = rng.random() < 0.8
     inplace = rng.random() < 0.5
     g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+    seed2 = rng.randrange(1 << 30) if KIND != "fp8" else 0
+    if ONLY >= 0 and it != ONLY:      # FUZZ_ONLY=n: replay case n of this seed alone (same random draws up to here)
+        continue
     if KIND != "fp8":
         # ---- int8 W8A8 (/root/reference/test_moe_int8.py:97-137: mean relative error < 1 %) and bf16 (test_moe.py:96-107) ----------
         E = min(E, 16)          # the torch oracle walks the experts
         topk = min(topk, E)
         tw, ids = routing(M, E, topk, kind, g)
         if KIND == "int8":
-            inp = recipes.moe_int8_inputs(M, N, K, E, topk, rng.randrange(1 << 30))
+            inp = recipes.moe_int8_inputs(M, N, K, E, topk, seed2)
             ref = moe.fused_experts_int8(inp["a"], inp["w1"], inp["w2"], inp["w1s"], inp["w2s"], tw, ids).float()
             scales = (inp["w1s"].cuda(), inp["w2s"].cuda())
         else:
-            inp = recipes.moe_bf16_inputs(M, N, K, E, topk, rng.randrange(1 << 30))
+            inp = recipes.moe_bf16_inputs(M, N, K, E, topk, seed2)
             ref = moe.fused_experts_f32(inp["a"], inp["w1"].float(), inp["w2"].float(), tw, ids)
             scales = (None, None)
         k = 2.0 / max(float(ref.abs().max()), 1e-6)
@@ -79,7 +83,21 @@ for it in range(iters):
         mre = float((o - ref).abs().mean() / ref.abs().mean().clamp_min(1e-12))
         path = _ops.last_path & _lib.PATH_TILE_MASK
         paths[path] = paths.get(path, 0) + 1
-        bad = (not ok_pred or mre > 0.01) if KIND == "int8" else (not ok_pred or rel > 6e-3)
+        # int8: the reference's own predicate (test_moe_int8.py:134-137, mean relative error < 1 %).  The elementwise allclose also
+        # held in every case but one of 600 -- seed 778, case 209: one token routed to the same expert twice with weights -3.58 and
+        # +3.40, so the two bf16-rounded rows cancel and leave 0.02 of rounding on elements near zero (both weight layouts give the
+        # same bits; replay with FUZZ_ONLY=209) -- so it is required only where no routed expert repeats in a token.
+        repeats = any(len(set(e for e in row if e >= 0)) < sum(1 for e in row if e >= 0) for row in ids.tolist())
+        bad = (mre > 0.01 or (not ok_pred and not repeats)) if KIND == "int8" else (not ok_pred or rel > 6e-3)
+        if ONLY >= 0:
+            err = (o - ref).abs()
+            tol = 1e-2 + 1e-2 * ref.bfloat16().float().abs()
+            idx = torch.nonzero(err > tol)
+            print(f"case {it}: ids={ids.tolist()} tw={[round(float(x), 3) for x in tw.flatten()]} max|ref|={float(ref.abs().max()):.3f} "
+                  f"elements over tolerance: {idx.shape[0]} of {o.numel()}, worst err {float(err.max()):.4f} at ref {float(ref.flatten()[err.argmax()]):.4f}")
+            o2 = ops.fused_experts_cpu(inp["a"].cuda(), inp["w1"].cuda(), inp["w2"].cuda(), tw.cuda(), ids.cuda(), False, KIND == "int8", False,
+                                       scales[0], scales[1], None, None, None, False).float().cpu()
+            print("  unpacked-weights call (another kernel): same bits" if torch.equal(o2, o) else f"  unpacked-weights call differs: max {float((o2 - o).abs().max()):.4f}, its worst err {float((o2 - ref).abs().max()):.4f}")
         if bad or not torch.isfinite(o).all():
             fails += 1
             print(f"FAIL {KIND} it={it} M={M} N={N} K={K} E={E} topk={topk} {kind} packed={packed} inplace={inplace} path={_ops.last_path:#x} "
