@@ -127,3 +127,28 @@ def test_grouped_topk_exact_ids_on_separated_scores(ops):
         ow, oids = routing.grouped_topk(gating, topk, True, 1, 1)
         assert torch.equal(ids.cpu(), oids), dt
         assert torch.allclose(w.cpu(), ow, rtol=2e-5, atol=1e-7)
+
+
+def test_grouped_topk_ties_and_odd_shapes_bit_exact(ops):
+    """The picks run on 64-bit (value, ~index) keys (topk.hip): tie-heavy logits (a handful of levels, +0 and -0 among them, or all
+    equal), expert counts that are not powers of two, every group / top-k split, selections that run out of selected-group experts
+    -- ids must equal the oracle's (larger value, then lower index) bit for bit.  tools/fuzz_topk.py is the long form."""
+    import random
+    rng = random.Random(99)
+    for it in range(60):
+        E = rng.choice([4, 8, 24, 64, 96, 128, 160, 256, 384, 1024])
+        G = rng.choice([g for g in (1, 2, 3, 4, 8, 16, 32, 64) if E % g == 0 and g <= E])
+        topk_group, topk = rng.randint(1, G), rng.randint(1, min(E, 12))
+        M = rng.choice([1, 5, 17, 64])
+        dt = rng.choice([torch.float32, torch.bfloat16, torch.float16])
+        g = torch.Generator().manual_seed(rng.randrange(1 << 30))
+        if rng.random() < 0.2:
+            gating = torch.zeros(M, E)
+        else:
+            levels = torch.tensor([-2.5, -1.0, -0.0, 0.0, 0.5, 0.5, 3.0])
+            gating = levels[torch.randint(0, len(levels), (M, E), generator=g)]
+        gating = gating.to(dt)
+        ow, oids = routing.grouped_topk(gating, topk, True, G, topk_group)
+        w, ids = ops.grouped_topk_cpu(gating.cuda(), gating.cuda(), topk, True, G, topk_group, 0, None, None)
+        assert torch.equal(ids.cpu().to(torch.int32), oids), f"case {it}: E={E} G={G} topk_group={topk_group} topk={topk} {dt}"
+        assert torch.allclose(torch.nan_to_num(w.cpu()), torch.nan_to_num(ow), rtol=2e-5, atol=1e-6)
