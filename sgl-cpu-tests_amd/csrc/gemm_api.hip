@@ -122,7 +122,7 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act, bool fp8_s
         if (km > ks) ks = km;
         const int kb = bf16_mid_ksplit(M, N, K);
         if (kb > ks) ks = kb;
-        const int ki = i8_mid_ksplit(M, N, K);
+        const int ki = i8_mid_dense_ksplit(M, N, K);
         if (ki > ks) ks = ki;
         if (M >= 192) {                                     // 256-row fp8 tile kernel with K ranges
             const int kt = tuned_fp8_ksplit(M, N, K);
@@ -827,9 +827,12 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         }
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
     }
-    // W8A8 at decode sizes (M <= 128): weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)
+    // W8A8 at decode sizes (M <= 128) and, while the 256-row kernel below would have only a handful of workgroups, up to
+    // SGLK_DENSE_MID_MAX rows: weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)
     if (a->wtype == SGLK_W_INT8 && a->packed && !knobs().force_generic && !knobs().no_i8_mid) {
-        const int ks = i8_mid_ksplit(M, N, K);
+        const bool few = knobs().i8_dense_mid_wgs > 0 && M < knobs().dense_mid_max &&
+                         (N % 256 != 0 || ceil_div(M, 256) * (int64_t)(N / 256) <= knobs().i8_dense_mid_wgs);
+        const int ks = M <= 128 ? i8_mid_ksplit(M, N, K) : (few ? i8_mid_dense_ksplit(M, N, K) : 0);
         if (ks >= 1) {
             const int8_t* xq = (const int8_t*)a->x;
             int64_t xq_stride = a->x_stride;

@@ -264,7 +264,7 @@ int bf16_mid_ksplit(int M, int N, int K) {
         const int ks = kblocks / per;
         if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
         best = ks;
-        if (tiles * ks >= 512) break;
+        if (tiles * ks >= (M > 64 ? knobs().bf16_mid_target : 512)) break;
     }
     return best;
 }

@@ -337,17 +337,37 @@ int i8_mid_ksplit(int M, int N, int K) {
     return best;
 }
 
+// Dense GEMMs above 128 rows: rows [128 i, 128 i + 128) are the kernel's PLAIN row tiles; the same range policy over all tiles.
+// (The 256-row tile kernel has ceil(M / 256) x N / 256 workgroups and takes one tile's time -- K / 64 stages -- however few they are:
+// 160 x 4096 x 4096 ran 55 us there against 20 us here at 128 rows.)
+int i8_mid_dense_ksplit(int M, int N, int K) {
+    if (M <= gimid::kTM) return i8_mid_ksplit(M, N, K);
+    if (M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;
+    const int kblocks = K >> 7;
+    const int64_t tiles = (int64_t)ceil_div(M, gimid::kTM) * (N / 128);
+    const int per_min = kblocks >= 4 ? 4 : 2;
+    int best = 0;
+    for (int per = kblocks; per >= per_min; per -= 2) {
+        if (kblocks % per != 0) continue;
+        const int ks = kblocks / per;
+        if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
+        best = ks;
+        if (tiles * ks >= 512) break;
+    }
+    return best;
+}
+
 int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
-    if (p.K % 128 != 0 || p.N % 128 != 0 || p.M > gimid::kTM || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
+    if (p.K % 128 != 0 || p.N % 128 != 0 || p.M >= 1024 || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
         (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial_i32)) || (!p.out && !p.partial_i32))
         SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_mid(plain): M=%d N=%d K=%d with %d ranges not supported", p.M, p.N, p.K, nsplit);
     if (p.M == 0) return SGLK_OK;
     I8GemmParams q = p;
     q.n_tiles = p.N >> 7;
     q.scale_rows = p.N;
-    const int64_t blocks = (int64_t)q.n_tiles * nsplit;
+    const int64_t blocks = (int64_t)ceil_div(p.M, gimid::kTM) * q.n_tiles * nsplit;
     hipLaunchKernelGGL((gimid::gemm_i8_mid_kernel<MODE_PLAIN, false>), dim3((unsigned)blocks), dim3(512), gimid::kLds, stream, q);
     SGLK_CHECK_LAUNCH("gemm_i8_mid(plain)");
     if (nsplit > 1 && p.out) {   // p.out == nullptr: the caller reduces the partials itself (shared expert)

@@ -17,6 +17,8 @@ struct Knobs {
     int mid_lo = 8, mid_hi = 0;   // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256; mid_hi 0 = by the experts' size (pick_tile_m)
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
     bool no_i8_mid = false;      // SGLK_NO_I8_MID
+    int bf16_mid_target = 512;   // SGLK_BF16_MID_TARGET: workgroups the dense bf16 weight-streaming kernel's split-K aims at above 64 rows (A/B)
+    int i8_dense_mid_wgs = 16;   // SGLK_I8_DENSE_MID_WGS: dense int8 above 128 rows stays on the weight-streaming kernel while the 256-row kernel would have at most this many workgroups (0 = round-2 policy: 128 rows)
     bool no_bf16_mid = false;    // SGLK_NO_BF16_MID
     int tail_split = -1;         // SGLK_TAIL_SPLIT: 0 = off, 1 = on the caller's stream, unset = caller's aux stream if given
     int mid_down2 = -1;          // SGLK_MID_DOWN2: 0 = one column tile per workgroup

@@ -226,6 +226,7 @@ struct GenericGemmParams {
 int launch_gemm_i8_mid(int mode, const I8GemmParams& p, int max_mtiles, hipStream_t stream);
 // decode-size dense W8A8 (M <= 128): 0 = shape not taken, else the number of K ranges; the launch includes the exact reduce
 int i8_mid_ksplit(int M, int N, int K);
+int i8_mid_dense_ksplit(int M, int N, int K);   // dense form: several 128-row tiles (M < 1024); equals i8_mid_ksplit up to 128 rows
 int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream);   // p.out == nullptr: partials only (no reduce)
 int launch_i8_reduce_silu_mul(const int32_t* partial, int ksplit, int rows, int n, const float* xs, const float* ws, float* out,
                               hipStream_t stream);

@@ -390,6 +390,39 @@ def test_int8_mfma_gemm_is_exact(ops, shape):
     assert ref_pred(ogemm.int8_scaled_mm(Aq, As, Bq, Bs, bias).bfloat16(), out)
 
 
+@pytest.mark.parametrize("shape", [(129, 4096, 4096, True), (160, 2048, 6144, False), (256, 4096, 4096, False), (300, 384, 768, True),
+                                   (512, 4096, 4096, True), (1000, 640, 1024, False)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_int8_dense_between_129_and_1023_rows_is_exact(ops, knob, shape):
+    """int8_scaled_mm_cpu / _with_quant above 128 rows while the 256-row kernel would have only a handful of workgroups: several
+    128-row tiles of csrc/gemm_i8_mid.hip with exact int32 split-K partials.  BIT FOR BIT the exact-integer evaluation of the
+    oracle's expression (/root/reference/test_gemm_int8.py:41-47), and bit-identical to the round-2 policy (the 256-row kernel,
+    SGLK_I8_DENSE_MID_WGS=0)."""
+    M, N, K, has_bias = shape
+    g = torch.Generator().manual_seed(M + 2 * N + K)
+    A = (torch.randn(M, K, generator=g) / 10).bfloat16()
+    Bq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    Bs = torch.rand(N, generator=g) * 1e-2 + 1e-4
+    bias = torch.randn(N, generator=g) if has_bias else None
+    Aq, As = ogemm.per_token_quant_int8(A)
+    acc = (Aq.double() @ Bq.double().t()).long()
+    exact = As.float().view(-1, 1) * acc.to(torch.float32) * Bs.view(1, -1)
+    if bias is not None:
+        exact = exact + bias.view(1, -1)
+    exact = exact.bfloat16()
+    wp = ops.convert_weight_packed(Bq.cuda())
+    b = bias.cuda() if bias is not None else None
+    knob(SGLK_I8_DENSE_MID_WGS=64)          # every shape of this test on the weight-streaming kernel
+    out = ops.int8_scaled_mm_cpu(Aq.cuda(), wp, As.cuda(), Bs.cuda(), b, torch.bfloat16, True)
+    assert torch.equal(out.cpu(), exact)
+    fused = ops.int8_scaled_mm_with_quant(A.cuda(), wp, Bs.cuda(), b, torch.bfloat16, True)
+    assert torch.equal(fused, out)
+    knob(SGLK_I8_DENSE_MID_WGS=None)        # the shipped policy
+    assert torch.equal(ops.int8_scaled_mm_cpu(Aq.cuda(), wp, As.cuda(), Bs.cuda(), b, torch.bfloat16, True), out)
+    knob(SGLK_I8_DENSE_MID_WGS=0)           # round-2 policy: the 256-row kernel from 129 rows on
+    assert torch.equal(ops.int8_scaled_mm_cpu(Aq.cuda(), wp, As.cuda(), Bs.cuda(), b, torch.bfloat16, True), out)
+
+
 @pytest.mark.parametrize("shape", [(192, 256, 128, False), (1000, 512, 1024, True), (300, 768, 2080, True), (2049, 1536, 2048, False)],
                          ids=lambda s: "x".join(map(str, s[:3])))
 def test_bf16_packed_linear_on_tuned_kernel(ops, shape):
@@ -398,6 +431,31 @@ def test_bf16_packed_linear_on_tuned_kernel(ops, shape):
     rounding noise to the row-major (generic engine) path."""
     M, N, K, has_bias = shape
     g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, generator=g) / 8).bfloat16()
+    w = (torch.randn(N, K, generator=g) / 8).bfloat16()
+    bias = torch.randn(N, generator=g) if has_bias else None
+    ref = x.float() @ w.float().t()
+    if bias is not None:
+        ref = ref + bias
+    wp = ops.convert_weight_packed(w.cuda())
+    b = bias.cuda() if bias is not None else None
+    out = ops.weight_packed_linear(x.cuda(), wp, b, True)
+    assert ref_pred(ref, out)
+    assert rel_rms(out, ref) < 3e-3
+    plain = ops.weight_packed_linear(x.cuda(), w.cuda(), b, False)
+    assert rel_rms(out, plain) < 3e-3
+
+
+@pytest.mark.parametrize("shape", [(128, 4096, 4096, False), (65, 512, 1024, True), (100, 384, 768, True), (128, 256, 384, False),
+                                   (160, 2048, 1024, True), (97, 12288, 2048, False)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_bf16_packed_linear_between_65_and_191_rows(ops, shape):
+    """weight_packed_linear with packed weights at 65 ... 191 rows (BASELINE config 0 is (128, 4096, 4096),
+    /root/reference/test_gemm.py:51-72) runs csrc/gemm_bf16_mid.hip with 128-row tiles and split-K; oracle: fp32 matmul of
+    the bf16 operands (+ bias) rounded once (/root/reference/test_gemm.py:15-21), reference predicate; and within rounding
+    noise of the row-major (generic engine) path."""
+    M, N, K, has_bias = shape
+    g = torch.Generator().manual_seed(M * 5 + N + K)
     x = (torch.randn(M, K, generator=g) / 8).bfloat16()
     w = (torch.randn(N, K, generator=g) / 8).bfloat16()
     bias = torch.randn(N, generator=g) if has_bias else None

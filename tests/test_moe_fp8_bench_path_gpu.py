@@ -172,7 +172,7 @@ def test_grid_cap_drives_tile_loop_and_tickets(ops, knob, name, cap):
         assert torch.equal(out, base), f"{name}: capped persistent launch differs from one workgroup per tile (run {rep})"
 
 
-def test_row_strided_hidden_and_second_device_guard(ops, qwen3):
+def test_row_strided_hidden_equals_contiguous(ops, qwen3):
     """hidden_states as a row-strided view (stride > K): the 256-row kernel addresses rows by the stride, and its 32-bit
     offsets are guarded by M * stride; result equals the contiguous call bit for bit."""
     M = 2048
