@@ -39,7 +39,7 @@ bool dense_prefers_mid(int M, int N, int wtype) {
     if (M < 192) return true;
     if (M >= knobs().dense_mid_max) return false;
     const int64_t wgs = ceil_div(M, 256) * (int64_t)(N / 256);
-    return wgs <= (wtype == SGLK_W_FP8_E4M3 ? 96 : 32);
+    return wgs <= (wtype == SGLK_W_FP8_E4M3 ? knobs().dense_mid_wgs_fp8 : knobs().dense_mid_wgs_bf16);
 }
 
 // Split-K for the 256-row fp8 tile kernel in dense mode: with ceil(M / 256) x N / 256 workgroups well under the CU count the
@@ -827,11 +827,14 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         }
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
     }
-    // W8A8 at decode sizes (M <= 128) and, while the 256-row kernel below would have only a handful of workgroups, up to
-    // SGLK_DENSE_MID_MAX rows: weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip)
+    // W8A8 at decode sizes and, while the 256-row kernel below would have at most 32 workgroups (or cannot run: M < 192), up to
+    // SGLK_DENSE_MID_MAX rows: weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip).  Same-box A/B
+    // (tools/ab_i8_dense_mid.py, profiles/r03_ab_dense_129_1000.txt): 160 x 4096 x 4096 55 -> 21 us (the generic engine ran 129 ... 191
+    // rows), 512 x 4096 x 4096 38 -> 29, 512 x 2048 x 6144 36 -> 25; 384 x 5120 x 2048 (40 workgroups) and 12288-wide layers from 192
+    // rows on are faster on the tile kernel and stay there
     if (a->wtype == SGLK_W_INT8 && a->packed && !knobs().force_generic && !knobs().no_i8_mid) {
         const bool few = knobs().i8_dense_mid_wgs > 0 && M < knobs().dense_mid_max &&
-                         (N % 256 != 0 || ceil_div(M, 256) * (int64_t)(N / 256) <= knobs().i8_dense_mid_wgs);
+                         (M < 192 || N % 256 != 0 || ceil_div(M, 256) * (int64_t)(N / 256) <= knobs().i8_dense_mid_wgs);
         const int ks = M <= 128 ? i8_mid_ksplit(M, N, K) : (few ? i8_mid_dense_ksplit(M, N, K) : 0);
         if (ks >= 1) {
             const int8_t* xq = (const int8_t*)a->x;

@@ -259,12 +259,20 @@ int bf16_mid_ksplit(int M, int N, int K) {
     const int64_t tiles = (int64_t)ceil_div(M, M <= 64 ? 64 : 128) * (N / 128);
     const int per_min = kblocks >= 4 ? 4 : 2;
     int best = 0;
+    if (M > 64 && knobs().bf16_mid_target == 0) {
+        // The 128-row build holds ONE workgroup per CU (158-166 VGPRs), so the launch runs ceil(workgroups / CUs) rounds, each as
+        // long as one range plus ~3 K blocks' worth of prologue and epilogue: take the split that minimises rounds x (blocks per
+        // range + 3).  Aiming at 512 workgroups whatever the rounds (the rule below) ran two rounds of short ranges: 160 x 4096 x
+        // 4096 32.5 -> 25.5 us, 512 x 4096 x 4096 48.0 -> 38.9 (tools/ab_bf16_mid_target.py, profiles/r03_ab_dense_129_1000.txt).
+        return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count());
+    }
+    const int target = M > 64 && knobs().bf16_mid_target > 0 ? knobs().bf16_mid_target : 512;
     for (int per = kblocks; per >= per_min; per -= 2) {
         if (kblocks % per != 0) continue;
         const int ks = kblocks / per;
         if (ks > 32 || (int64_t)ks * M * N * 4 > (64ll << 20)) continue;
         best = ks;
-        if (tiles * ks >= (M > 64 ? knobs().bf16_mid_target : 512)) break;
+        if (tiles * ks >= target) break;
     }
     return best;
 }

@@ -325,6 +325,7 @@ int i8_mid_ksplit(int M, int N, int K) {
     if (M <= 0 || M > gimid::kTM || N % 128 != 0 || K % 256 != 0) return 0;
     const int kblocks = K >> 7;
     const int64_t tiles = N / 128;
+    if (knobs().mid_dense_model > 0) return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count() * (knobs().mid_dense_model == 1 ? 2 : 1));
     const int per_min = kblocks >= 4 ? 4 : 2;
     int best = 0;
     for (int per = kblocks; per >= per_min; per -= 2) {
@@ -345,6 +346,7 @@ int i8_mid_dense_ksplit(int M, int N, int K) {
     if (M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;
     const int kblocks = K >> 7;
     const int64_t tiles = (int64_t)ceil_div(M, gimid::kTM) * (N / 128);
+    if (knobs().mid_dense_model > 0) return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count() * (knobs().mid_dense_model == 1 ? 2 : 1));
     const int per_min = kblocks >= 4 ? 4 : 2;
     int best = 0;
     for (int per = kblocks; per >= per_min; per -= 2) {

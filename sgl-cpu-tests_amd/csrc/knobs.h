@@ -17,8 +17,10 @@ struct Knobs {
     int mid_lo = 8, mid_hi = 0;   // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256; mid_hi 0 = by the experts' size (pick_tile_m)
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
     bool no_i8_mid = false;      // SGLK_NO_I8_MID
-    int bf16_mid_target = 512;   // SGLK_BF16_MID_TARGET: workgroups the dense bf16 weight-streaming kernel's split-K aims at above 64 rows (A/B)
-    int i8_dense_mid_wgs = 16;   // SGLK_I8_DENSE_MID_WGS: dense int8 above 128 rows stays on the weight-streaming kernel while the 256-row kernel would have at most this many workgroups (0 = round-2 policy: 128 rows)
+    int dense_mid_wgs_bf16 = 32, dense_mid_wgs_fp8 = 96;   // SGLK_DENSE_MID_WGS_BF16 / _FP8: from 192 rows on the weight-streaming kernel is taken while the 256-row kernel would have at most this many workgroups
+    int mid_dense_model = 2;     // SGLK_MID_DENSE_MODEL: split-K of the dense fp8 / int8 weight-streaming kernels: 2 = rounds model on CUs slots, 1 = on 2 x CUs slots, 0 = aim at 512 workgroups (before)
+    int bf16_mid_target = 0;     // SGLK_BF16_MID_TARGET: 0 = split-K of the dense bf16 weight-streaming kernel above 64 rows by the rounds model; n = aim at n workgroups (512 = before; profiles/r03_ab_dense_129_1000.txt)
+    int i8_dense_mid_wgs = 32;   // SGLK_I8_DENSE_MID_WGS: dense int8 above 128 rows stays on the weight-streaming kernel while the 256-row kernel would have at most this many workgroups, and always below 192 rows (0 = round-2 policy: up to 128 rows)
     bool no_bf16_mid = false;    // SGLK_NO_BF16_MID
     int tail_split = -1;         // SGLK_TAIL_SPLIT: 0 = off, 1 = on the caller's stream, unset = caller's aux stream if given
     int mid_down2 = -1;          // SGLK_MID_DOWN2: 0 = one column tile per workgroup
@@ -57,6 +59,27 @@ const Knobs& knobs();
 
 // compute units of the CURRENT device (cached per device)
 int device_cu_count();
+// split-K by the rounds model (weight-streaming dense kernels): the launch runs ceil(tiles x ranges / slots) rounds, each as long as one
+// range plus ~3 K blocks' worth of prologue and epilogue; a split adds the reduce launch (~3 blocks) and the fp32 / int32 partials' round
+// trip (~7 MB per block time).  Returns the range count with the lowest cost (0 = none allowed).  Fitted to same-box A/Bs at 1 ... 1000
+// rows x five layer shapes (tools/ab_mid_dense_model.py, tools/ab_bf16_mid_target.py; profiles/r03_ab_dense_129_1000.txt)
+inline int splitk_by_rounds(int kblocks, long long tiles, int M, int N, int slots, int per_cap = 1 << 30) {
+    const int per_min = kblocks >= 4 ? 4 : 2;
+    int best = 0;
+    long long best_cost = -1;
+    for (int per = kblocks; per >= per_min; per -= 2) {
+        if (kblocks % per != 0 || per > per_cap) continue;
+        const int ks = kblocks / per;
+        if (ks > 32 || (long long)ks * M * N * 4 > (64ll << 20)) continue;
+        long long cost = ((tiles * ks + slots - 1) / slots) * (per + 3) * 16;   // sixteenths of a block time
+        if (ks > 1) cost += 48 + (long long)ks * M * N * 128 / 7000000;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = ks;
+        }
+    }
+    return best;
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (call site, device); `done` is the call site's bit mask
 int ensure_dyn_lds(const void* func, int bytes, std::atomic<unsigned>& done, const char* what);

@@ -578,6 +578,7 @@ int mid_dense_ksplit(int M, int N, int K) {
     if (M <= 0 || M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;   // capability; the dispatch policy is dense_prefers_mid
     const int kblocks = K >> 7;
     const int64_t tiles = (int64_t)ceil_div(M, kMidTileM) * (N / 128);
+    if (knobs().mid_dense_model > 0) return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count() * (knobs().mid_dense_model == 1 ? 2 : 1), 32);
     int best = 0;
     const int per_min = kblocks >= 4 ? 4 : 2;               // a range shorter than 4 blocks is all prologue
     for (int per = kblocks; per >= per_min; per -= 2) {    // longest ranges first
