@@ -40,10 +40,10 @@ void read_env() {
     k.mid_bf16_hi = env_int("SGLK_MID_BF16_HI", 44);
     k.force_generic = env_set("SGLK_FORCE_GENERIC");
     k.no_i8_mid = env_set("SGLK_NO_I8_MID");
-    k.i8_dense_mid_wgs = env_int("SGLK_I8_DENSE_MID_WGS", 32);
+    k.i8_dense_mid_wgs = env_int("SGLK_I8_DENSE_MID_WGS", 64);
     k.bf16_mid_target = env_int("SGLK_BF16_MID_TARGET", 0);
     k.mid_dense_model = env_int("SGLK_MID_DENSE_MODEL", 2);
-    k.dense_mid_wgs_bf16 = env_int("SGLK_DENSE_MID_WGS_BF16", 32);
+    k.dense_mid_wgs_bf16 = env_int("SGLK_DENSE_MID_WGS_BF16", 60);
     k.dense_mid_wgs_fp8 = env_int("SGLK_DENSE_MID_WGS_FP8", 96);
     k.no_bf16_mid = env_set("SGLK_NO_BF16_MID");
     k.tail_split = env_int("SGLK_TAIL_SPLIT", -1);

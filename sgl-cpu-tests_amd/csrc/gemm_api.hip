@@ -34,7 +34,9 @@ bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int
 // and loses to the streaming kernels by 2-4x until it can fill a good part of the chip (same-box A/B, tools/ab_dense_mid.py,
 // profiles/r02_ab_dense_mid.txt: 192 x 4096 x 4096 fp8 0.096 -> 0.025 ms, bf16 0.072 -> 0.036; 1000 x 2048 x 6144 fp8 0.118 -> 0.053;
 // a 12288-wide bf16 layer stays on the 256-row kernel).  Without split-K that kernel's time is one tile's time (K / 64 stages)
-// however few tiles there are.
+// however few tiles there are.  Round 3, after the split-K of the streaming kernels went to the rounds model (knobs.h: splitk_by_rounds):
+// crossover re-measured (tools/ab_dense_crossover.py, profiles/r03_ab_dense_crossover.txt): bf16 up to 60 workgroups of the tile kernel
+// (384 x 5120 x 2048: 41 -> 26 us; 192-256 x 12288 x 2048: 41 -> 28), fp8 up to 96 as before, int8 up to 64 (gemm_api.hip below).
 bool dense_prefers_mid(int M, int N, int wtype) {
     if (M < 192) return true;
     if (M >= knobs().dense_mid_max) return false;
@@ -827,7 +829,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         }
         return launch_gemm_bf16_256(MODE_PLAIN, q, (int)ceil_div(M, 256), s);
     }
-    // W8A8 at decode sizes and, while the 256-row kernel below would have at most 32 workgroups (or cannot run: M < 192), up to
+    // W8A8 at decode sizes and, while the 256-row kernel below would have at most 64 workgroups (or cannot run: M < 192), up to
     // SGLK_DENSE_MID_MAX rows: weight-streaming int8 kernel, exact int32 split-K partials (gemm_i8_mid.hip).  Same-box A/B
     // (tools/ab_i8_dense_mid.py, profiles/r03_ab_dense_129_1000.txt): 160 x 4096 x 4096 55 -> 21 us (the generic engine ran 129 ... 191
     // rows), 512 x 4096 x 4096 38 -> 29, 512 x 2048 x 6144 36 -> 25; 384 x 5120 x 2048 (40 workgroups) and 12288-wide layers from 192

@@ -17,10 +17,10 @@ struct Knobs {
     int mid_lo = 8, mid_hi = 0;   // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256; mid_hi 0 = by the experts' size (pick_tile_m)
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine
     bool no_i8_mid = false;      // SGLK_NO_I8_MID
-    int dense_mid_wgs_bf16 = 32, dense_mid_wgs_fp8 = 96;   // SGLK_DENSE_MID_WGS_BF16 / _FP8: from 192 rows on the weight-streaming kernel is taken while the 256-row kernel would have at most this many workgroups
+    int dense_mid_wgs_bf16 = 60, dense_mid_wgs_fp8 = 96;   // SGLK_DENSE_MID_WGS_BF16 / _FP8: from 192 rows on the weight-streaming kernel is taken while the 256-row kernel would have at most this many workgroups
     int mid_dense_model = 2;     // SGLK_MID_DENSE_MODEL: split-K of the dense fp8 / int8 weight-streaming kernels: 2 = rounds model on CUs slots, 1 = on 2 x CUs slots, 0 = aim at 512 workgroups (before)
     int bf16_mid_target = 0;     // SGLK_BF16_MID_TARGET: 0 = split-K of the dense bf16 weight-streaming kernel above 64 rows by the rounds model; n = aim at n workgroups (512 = before; profiles/r03_ab_dense_129_1000.txt)
-    int i8_dense_mid_wgs = 32;   // SGLK_I8_DENSE_MID_WGS: dense int8 above 128 rows stays on the weight-streaming kernel while the 256-row kernel would have at most this many workgroups, and always below 192 rows (0 = round-2 policy: up to 128 rows)
+    int i8_dense_mid_wgs = 64;   // SGLK_I8_DENSE_MID_WGS: dense int8 above 128 rows stays on the weight-streaming kernel while the 256-row kernel would have at most this many workgroups, and always below 192 rows (0 = round-2 policy: up to 128 rows)
     bool no_bf16_mid = false;    // SGLK_NO_BF16_MID
     int tail_split = -1;         // SGLK_TAIL_SPLIT: 0 = off, 1 = on the caller's stream, unset = caller's aux stream if given
     int mid_down2 = -1;          // SGLK_MID_DOWN2: 0 = one column tile per workgroup

@@ -412,7 +412,7 @@ def test_int8_dense_between_129_and_1023_rows_is_exact(ops, knob, shape):
     exact = exact.bfloat16()
     wp = ops.convert_weight_packed(Bq.cuda())
     b = bias.cuda() if bias is not None else None
-    knob(SGLK_I8_DENSE_MID_WGS=64)          # every shape of this test on the weight-streaming kernel
+    knob(SGLK_I8_DENSE_MID_WGS=100000)      # every shape of this test on the weight-streaming kernel
     out = ops.int8_scaled_mm_cpu(Aq.cuda(), wp, As.cuda(), Bs.cuda(), b, torch.bfloat16, True)
     assert torch.equal(out.cpu(), exact)
     fused = ops.int8_scaled_mm_with_quant(A.cuda(), wp, Bs.cuda(), b, torch.bfloat16, True)
