@@ -29,6 +29,13 @@ bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int
            (int64_t)M * x_stride * 2 < (1ll << 32) && (int64_t)R * C < (1ll << 32) && !knobs().force_generic;
 }
 
+// int8 shared expert on the weight-streaming kernel: one 128-row tile always, several (M < SGLK_SHARED_I8_MID_MAX) while that beats the
+// 256-row kernels' one-tile time (2048 x 7168: 129 ... 191 rows ran the generic engine, 251 us; 192 ... 1024 rows ~117 us whatever M)
+static int shared_i8_ksplit(int M, int N, int K) {
+    if (M <= 128) return i8_mid_ksplit(M, N, K);
+    return M < knobs().shared_i8_mid_max ? i8_mid_dense_ksplit(M, N, K) : 0;
+}
+
 // Dense GEMM, packed weights: weight-streaming (split-K) kernel or 256-row tile kernel?  Below 192 rows always the former.  From
 // there to SGLK_DENSE_MID_MAX (1024) the 256-row kernel only has ceil(M / 256) x N / 256 workgroups -- 16 for a 4096-wide layer --
 // and loses to the streaming kernels by 2-4x until it can fill a good part of the chip (same-box A/B, tools/ab_dense_mid.py,
@@ -106,7 +113,7 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act, bool fp8_s
         const int j1 = bf16_mid_ksplit(M, 2 * N, K), j2 = bf16_mid_ksplit(M, K, N);    // bf16 weights: same scheme
         if (j1 > k1) k1 = j1;
         if (j2 > k2) k2 = j2;
-        const int i1 = i8_mid_ksplit(M, 2 * N, K), i2 = i8_mid_ksplit(M, K, N);      // int8 weights: int32 partials, same size
+        const int i1 = shared_i8_ksplit(M, 2 * N, K), i2 = shared_i8_ksplit(M, K, N);      // int8 weights: int32 partials, same size
         if (i1 > k1) k1 = i1;
         if (i2 > k2) k2 = i2;
         if (k1 >= 1 && k2 >= 1) {
@@ -385,7 +392,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
         return launch_gemm_bf16_256(MODE_PLAIN, q2, t256, s);
     }
     if (big_common && i8 && N >= 256 && (int64_t)M * K < (1ll << 32) &&
-        (i8_mid_ksplit(M, 2 * N, K) < 1 || i8_mid_ksplit(M, K, N) < 1 || knobs().no_i8_mid)) {
+        (shared_i8_ksplit(M, 2 * N, K) < 1 || shared_i8_ksplit(M, K, N) < 1 || knobs().no_i8_mid)) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
         rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
@@ -438,10 +445,10 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
         q2.addend_scale = a->routed_scaling_factor;
         return launch_gemm_i8_256(MODE_PLAIN, q2, t256, s);
     }
-    // int8 W8A8, decode sizes (M <= 128): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
+    // int8 W8A8, decode sizes and up to SGLK_SHARED_I8_MID_MAX rows (shared_i8_ksplit): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
     // (fp32 ic1), quantise ic1, down as int32 partials, reduce with the scales + fused_out * routed_scaling_factor
     if (i8 && (a->packed & 3) == 3 && !knobs().force_generic && !knobs().no_i8_mid) {
-        const int k1 = i8_mid_ksplit(M, 2 * N, K), k2 = i8_mid_ksplit(M, K, N);
+        const int k1 = shared_i8_ksplit(M, 2 * N, K), k2 = shared_i8_ksplit(M, K, N);
         if (k1 >= 1 && k2 >= 1) {
             int32_t* partial = (int32_t*)(ws + w.partial);
             int8_t* xq = (int8_t*)(ws + w.xq);

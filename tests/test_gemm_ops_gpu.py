@@ -177,7 +177,7 @@ def test_shared_expert_bf16_and_int8(ops, case):
     assert ref_pred(g["ref_int8"], res8), name
 
 
-@pytest.mark.parametrize("M", [200, 700, 1100, 1300])
+@pytest.mark.parametrize("M", [129, 200, 500, 700, 1100, 1300])
 def test_shared_expert_bf16_and_int8_packed_at_prefill_sizes(ops, knob, M):
     """Packed bf16 / int8 weights from 192 rows on (bf16: from SGLK_SHARED_MID_MAX, below it the split-K passes) run on the tuned
     256-row kernels of fused_experts -- grouped form with one expert for gate_up + SiLU*mul, dense form with the fused_out addend for
