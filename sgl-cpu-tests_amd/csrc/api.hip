@@ -33,9 +33,10 @@ void read_env() {
     k.moe_tile_m = env_int("SGLK_MOE_TILE_M", 0);
     k.mid_lo = env_int("SGLK_MID_LO", 8);
     k.mid_hi = env_int("SGLK_MID_HI", 0);
-    k.dense_mid_max = env_int("SGLK_DENSE_MID_MAX", 1024);
+    k.dense_mid_max = env_int("SGLK_DENSE_MID_MAX", 2048);
     k.shared_mid_max = env_int("SGLK_SHARED_MID_MAX", 1024);
     k.shared_i8_mid_max = env_int("SGLK_SHARED_I8_MID_MAX", 1024);
+    k.shared_big_wgs = env_int("SGLK_SHARED_BIG_WGS", 64);
     k.no_tuned_splitk = env_set("SGLK_NO_TUNED_SPLITK");
     k.mid_i8_hi = env_int("SGLK_MID_I8_HI", 44);
     k.mid_bf16_hi = env_int("SGLK_MID_BF16_HI", 44);

@@ -31,9 +31,17 @@ bool tuned_dense_ok(int M, int R, int C, int wtype, int packed, int block_n, int
 
 // int8 shared expert on the weight-streaming kernel: one 128-row tile always, several (M < SGLK_SHARED_I8_MID_MAX) while that beats the
 // 256-row kernels' one-tile time (2048 x 7168: 129 ... 191 rows ran the generic engine, 251 us; 192 ... 1024 rows ~117 us whatever M)
-static int shared_i8_ksplit(int M, int N, int K) {
+// `width` = the expert's intermediate size (gate_up has 2 x width rows)
+static bool shared_rows_take_mid(int M, int width, int max_rows) {
+    if (M < max_rows) return true;
+    // from 1024 rows on: while the tile kernels' gate_up launch would have at most 64 workgroups (width 768: 74 -> 43-55 us at 1024 ...
+    // 2000 rows; width 2048 at 1024 rows 189 -> 149 us fp8, and the tile kernels from 1280 rows; profiles/r03_ab_rows_1024_2047.txt)
+    return max_rows >= 1024 && knobs().shared_big_wgs > 0 && M < kMidDenseMaxM &&
+           ceil_div(M, 256) * (int64_t)(2 * width / 256) <= knobs().shared_big_wgs;
+}
+static int shared_i8_ksplit(int M, int N, int K, int width) {
     if (M <= 128) return i8_mid_ksplit(M, N, K);
-    return M < knobs().shared_i8_mid_max ? i8_mid_dense_ksplit(M, N, K) : 0;
+    return shared_rows_take_mid(M, width, knobs().shared_i8_mid_max) ? i8_mid_dense_ksplit(M, N, K) : 0;
 }
 
 // Dense GEMM, packed weights: weight-streaming (split-K) kernel or 256-row tile kernel?  Below 192 rows always the former.  From
@@ -46,9 +54,12 @@ static int shared_i8_ksplit(int M, int N, int K) {
 // (384 x 5120 x 2048: 41 -> 26 us; 192-256 x 12288 x 2048: 41 -> 28), fp8 up to 96 as before, int8 up to 64 (gemm_api.hip below).
 bool dense_prefers_mid(int M, int N, int wtype) {
     if (M < 192) return true;
-    if (M >= knobs().dense_mid_max) return false;
+    if (M >= knobs().dense_mid_max || M >= kMidDenseMaxM) return false;
     const int64_t wgs = ceil_div(M, 256) * (int64_t)(N / 256);
-    return wgs <= (wtype == SGLK_W_FP8_E4M3 ? knobs().dense_mid_wgs_fp8 : knobs().dense_mid_wgs_bf16);
+    // from 1024 rows on the bf16 tile kernel splits K itself and wins from 40 workgroups on (1280 x 2048 x 6144: 58 vs 69 us); fp8 keeps
+    // its threshold up to 2047 rows (1280 x 4096 x 4096: 68 -> 55 us; profiles/r03_ab_rows_1024_2047.txt)
+    const int bf16_max = M >= 1024 && knobs().dense_mid_wgs_bf16 > 32 ? 32 : knobs().dense_mid_wgs_bf16;
+    return wgs <= (wtype == SGLK_W_FP8_E4M3 ? knobs().dense_mid_wgs_fp8 : bf16_max);
 }
 
 // Split-K for the 256-row fp8 tile kernel in dense mode: with ceil(M / 256) x N / 256 workgroups well under the CU count the
@@ -113,7 +124,7 @@ DenseWs plan_dense(int M, int N, int K, bool need_ic1, bool int8_act, bool fp8_s
         const int j1 = bf16_mid_ksplit(M, 2 * N, K), j2 = bf16_mid_ksplit(M, K, N);    // bf16 weights: same scheme
         if (j1 > k1) k1 = j1;
         if (j2 > k2) k2 = j2;
-        const int i1 = shared_i8_ksplit(M, 2 * N, K), i2 = shared_i8_ksplit(M, K, N);      // int8 weights: int32 partials, same size
+        const int i1 = shared_i8_ksplit(M, 2 * N, K, N), i2 = shared_i8_ksplit(M, K, N, N);      // int8 weights: int32 partials, same size
         if (i1 > k1) k1 = i1;
         if (i2 > k2) k2 = i2;
         if (k1 >= 1 && k2 >= 1) {
@@ -261,7 +272,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
     int* num_tiles = (int*)(ws + w.num_tiles);
     uint16_t* ic1 = (uint16_t*)(ws + w.ic1);
     // (up to SGLK_SHARED_MID_MAX rows the split-K passes below are taken even where the tile kernel could run)
-    const bool shared_mid = M < knobs().shared_mid_max && a->wtype == SGLK_W_FP8_E4M3 && a->block_k == 128 && a->block_n > 0 &&
+    const bool shared_mid = shared_rows_take_mid(M, N, knobs().shared_mid_max) && a->wtype == SGLK_W_FP8_E4M3 && a->block_k == 128 && a->block_n > 0 &&
                             a->block_n % 16 == 0 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
                             mid_dense_ksplit(M, 2 * N, K) >= 1 && mid_dense_ksplit(M, K, N) >= 1;
     if ((a->packed & 3) == 3 && N % 128 == 0 && !shared_mid &&
@@ -352,7 +363,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
                             ((uintptr_t)a->fused_out % 8) == 0 && (int64_t)4 * N * K < (1ll << 32) && (int64_t)M * N * 4 < (1ll << 32);
     if (big_common && a->wtype == SGLK_W_BF16 && a->hidden_stride % 8 == 0 && ((uintptr_t)a->hidden % 16) == 0 &&
         (int64_t)M * a->hidden_stride * 2 < (1ll << 32) &&
-        (M >= knobs().shared_mid_max || bf16_mid_ksplit(M, 2 * N, K) < 1 || bf16_mid_ksplit(M, K, N) < 1)) {
+        (!shared_rows_take_mid(M, N, knobs().shared_mid_max) || bf16_mid_ksplit(M, 2 * N, K) < 1 || bf16_mid_ksplit(M, K, N) < 1)) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
         rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
@@ -392,7 +403,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
         return launch_gemm_bf16_256(MODE_PLAIN, q2, t256, s);
     }
     if (big_common && i8 && N >= 256 && (int64_t)M * K < (1ll << 32) &&
-        (shared_i8_ksplit(M, 2 * N, K) < 1 || shared_i8_ksplit(M, K, N) < 1 || knobs().no_i8_mid)) {
+        (shared_i8_ksplit(M, 2 * N, K, N) < 1 || shared_i8_ksplit(M, K, N, N) < 1 || knobs().no_i8_mid)) {
         int* ident = (int*)(ws + w.ident);
         const int t256 = (int)ceil_div(M, 256);
         rc = launch_dense_tiles(M, 256, tile_info, num_tiles, ident, s);
@@ -448,7 +459,7 @@ int sglk::shared_expert_impl(const sglk_shared_expert_args* a, void* stream, con
     // int8 W8A8, decode sizes and up to SGLK_SHARED_I8_MID_MAX rows (shared_i8_ksplit): quantise x, gate_up as exact int32 split-K partials, reduce with the scales + SiLU*mul
     // (fp32 ic1), quantise ic1, down as int32 partials, reduce with the scales + fused_out * routed_scaling_factor
     if (i8 && (a->packed & 3) == 3 && !knobs().force_generic && !knobs().no_i8_mid) {
-        const int k1 = shared_i8_ksplit(M, 2 * N, K), k2 = shared_i8_ksplit(M, K, N);
+        const int k1 = shared_i8_ksplit(M, 2 * N, K, N), k2 = shared_i8_ksplit(M, K, N, N);
         if (k1 >= 1 && k2 >= 1) {
             int32_t* partial = (int32_t*)(ws + w.partial);
             int8_t* xq = (int8_t*)(ws + w.xq);
@@ -735,7 +746,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
     if (a->wtype == SGLK_W_FP8_E4M3 && a->packed && !a->x_is_int8 && a->out_type == SGLK_OUT_BF16 && a->block_k == 128 &&
         a->block_n > 0 && a->block_n % 16 == 0 && a->x_stride % 8 == 0 && ((uintptr_t)a->x % 16) == 0 && a->out_stride % 4 == 0 &&
         ((uintptr_t)a->out % 8) == 0 && (!a->bias || ((uintptr_t)a->bias % 16) == 0) && !knobs().force_generic) {
-        const int ks = mid_dense_ksplit(M, N, K);
+        const int ks = (M < 1024 || dense_prefers_mid(M, N, a->wtype)) ? mid_dense_ksplit(M, N, K) : 0;   // from 1024 rows on only by the policy's choice
         if (ks >= 1) {
             const int mt = (int)ceil_div(M, kMidTileM);
             MoeGemmParams t{};   // no tile table: the kernel derives the row tiles from split_rows
@@ -769,7 +780,7 @@ extern "C" int sglk_scaled_mm(const sglk_scaled_mm_args* a, void* stream) {
         (!a->bias || ((uintptr_t)a->bias % 16) == 0) && ((uintptr_t)a->w % 4) == 0 && !knobs().force_generic) {
         // from 192 rows on only when the 256-row kernel below would have too few workgroups (or cannot take the shape)
         const bool tuned_can = N % 256 == 0 && K % 32 == 0 && a->out_stride % 8 == 0 && ((uintptr_t)a->out % 16) == 0;
-        const int ks = (M < 192 || !tuned_can || dense_prefers_mid(M, N, a->wtype)) ? bf16_mid_ksplit(M, N, K) : 0;
+        const int ks = (M < 192 || (!tuned_can && M < 1024) || dense_prefers_mid(M, N, a->wtype)) ? bf16_mid_ksplit(M, N, K) : 0;
         if (ks >= 1) {
             BmidParams q{};
             q.x = (const uint16_t*)a->x;

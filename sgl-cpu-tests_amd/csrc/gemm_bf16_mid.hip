@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NW * 64, TM == 64 ? 4 : 2) void gemm_bf16_mid_kerne
 
 // 0 = shape not taken, else the number of K ranges (>= 1); same policy as mid_dense_ksplit
 int bf16_mid_ksplit(int M, int N, int K) {
-    if (M <= 0 || M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;   // capability; the dispatch policy is dense_prefers_mid
+    if (M <= 0 || M >= kMidDenseMaxM || N % 128 != 0 || K % 256 != 0) return 0;   // capability; the dispatch policy is dense_prefers_mid
     const int kblocks = K >> 7;
     const int64_t tiles = (int64_t)ceil_div(M, M <= 64 ? 64 : 128) * (N / 128);
     const int per_min = kblocks >= 4 ? 4 : 2;

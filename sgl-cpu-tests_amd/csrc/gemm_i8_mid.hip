@@ -343,7 +343,7 @@ int i8_mid_ksplit(int M, int N, int K) {
 // 160 x 4096 x 4096 ran 55 us there against 20 us here at 128 rows.)
 int i8_mid_dense_ksplit(int M, int N, int K) {
     if (M <= gimid::kTM) return i8_mid_ksplit(M, N, K);
-    if (M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;
+    if (M >= kMidDenseMaxM || N % 128 != 0 || K % 256 != 0) return 0;
     const int kblocks = K >> 7;
     const int64_t tiles = (int64_t)ceil_div(M, gimid::kTM) * (N / 128);
     if (knobs().mid_dense_model > 0) return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count() * (knobs().mid_dense_model == 1 ? 2 : 1));
@@ -362,7 +362,7 @@ int i8_mid_dense_ksplit(int M, int N, int K) {
 int launch_gemm_i8_mid_plain(const I8GemmParams& p, hipStream_t stream) {
     const int nsplit = p.ksplit > 1 ? p.ksplit : 1;
     const int kblocks = nsplit > 1 ? p.split_kblocks : p.K >> 7;
-    if (p.K % 128 != 0 || p.N % 128 != 0 || p.M >= 1024 || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
+    if (p.K % 128 != 0 || p.N % 128 != 0 || p.M >= kMidDenseMaxM || kblocks < 2 || kblocks % 2 != 0 || p.x_stride % 16 != 0 ||
         (nsplit > 1 && ((p.K >> 7) != nsplit * kblocks || !p.partial_i32)) || (!p.out && !p.partial_i32))
         SGLK_FAIL(SGLK_ERR_SHAPE, "gemm_i8_mid(plain): M=%d N=%d K=%d with %d ranges not supported", p.M, p.N, p.K, nsplit);
     if (p.M == 0) return SGLK_OK;

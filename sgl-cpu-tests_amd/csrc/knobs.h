@@ -11,9 +11,10 @@ namespace sglk {
 struct Knobs {
     int moe_tile_m = 0;          // SGLK_MOE_TILE_M: force the fp8 grouped-GEMM tiling (32 / 96 / 128 / 256); 0 = by batch size
     int no_tuned_splitk = 0;     // SGLK_NO_TUNED_SPLITK: the 256-row fp8 tile kernel never splits K in dense mode (A/B)
+    int shared_big_wgs = 64;     // SGLK_SHARED_BIG_WGS: shared expert from 1024 rows on stays on the weight-streaming kernels while the tile kernels' gate_up launch would have at most this many workgroups (0 = off)
     int shared_i8_mid_max = 1024;// SGLK_SHARED_I8_MID_MAX: int8 shared expert below this M runs on the weight-streaming int8 kernel (several 128-row tiles); 129 = round-2 policy
     int shared_mid_max = 1024;   // SGLK_SHARED_MID_MAX: fp8 shared expert below this M runs as split-K passes of the weight-streaming kernel
-    int dense_mid_max = 1024;    // SGLK_DENSE_MID_MAX: dense GEMMs below this M may take the weight-streaming kernels when the 256-row kernel would have few workgroups (192 = round-1 policy)
+    int dense_mid_max = 2048;    // SGLK_DENSE_MID_MAX: dense GEMMs below this M may take the weight-streaming kernels when the 256-row kernel would have few workgroups (192 = round-1 policy)
     int mid_i8_hi = 44, mid_bf16_hi = 44;   // SGLK_MID_I8_HI / SGLK_MID_BF16_HI: rows per expert below which int8 / bf16 experts take their weight-streaming kernels
     int mid_lo = 8, mid_hi = 0;   // SGLK_MID_LO / SGLK_MID_HI: crossovers (average rows per expert) stream -> mid -> 256; mid_hi 0 = by the experts' size (pick_tile_m)
     bool force_generic = false;  // SGLK_FORCE_GENERIC: every GEMM on the generic engine

@@ -575,7 +575,7 @@ int launch_moe_gemm_fp8w_mid(int mode, const MoeGemmParams& p, int max_mtiles, h
 // columns per workgroup, and the reduction cut into equal ranges of an even number of 128-wide blocks until about 512
 // workgroups exist (two per CU).  Returns 0 when the shape is not taken.
 int mid_dense_ksplit(int M, int N, int K) {
-    if (M <= 0 || M >= 1024 || N % 128 != 0 || K % 256 != 0) return 0;   // capability; the dispatch policy is dense_prefers_mid
+    if (M <= 0 || M >= kMidDenseMaxM || N % 128 != 0 || K % 256 != 0) return 0;   // capability; the dispatch policy is dense_prefers_mid
     const int kblocks = K >> 7;
     const int64_t tiles = (int64_t)ceil_div(M, kMidTileM) * (N / 128);
     if (knobs().mid_dense_model > 0) return splitk_by_rounds(kblocks, tiles, M, N, device_cu_count() * (knobs().mid_dense_model == 1 ? 2 : 1), 32);

@@ -7,6 +7,7 @@ namespace sglk {
 constexpr int kTileM = 128;        // tokens (slot rows) per tile of the 128x128 kernel
 constexpr int kStreamTileM = 32;   // tokens per tile of the weight-streaming small-M kernel
 constexpr int kI8MidTileM = 128;   // rows per tile (at most) of the int8 weight-streaming kernel (gemm_i8_mid.hip)
+constexpr int kMidDenseMaxM = 2048;   // dense / shared-expert forms of the weight-streaming kernels take fewer rows than this (the dispatch decides below it)
 constexpr int kMidTileM = 96;      // tokens per tile (at most) of the weight-streaming mid-M kernel
 
 enum { MODE_GATE_UP = 0, MODE_DOWN = 1, MODE_PLAIN = 2 };   // PLAIN: out[pos] = x.W^T (+bias) (+addend*scale), dense

@@ -427,6 +427,44 @@ def test_int8_dense_between_129_and_1023_rows_is_exact(ops, knob, shape):
         assert ref_pred(out.float().cpu(), old)
 
 
+@pytest.mark.parametrize("shape", [(1024, 2048, 1024, True), (1500, 1024, 2048, False), (2047, 768, 512, True)],
+                         ids=lambda s: "x".join(map(str, s[:3])))
+def test_dense_gemms_between_1024_and_2047_rows_on_the_streaming_kernels(ops, knob, shape):
+    """From 1024 to 2047 rows the dense GEMMs stay on the weight-streaming kernels while the 256-row kernels would have few
+    workgroups (SGLK_DENSE_MID_MAX = 2048).  Every weight type against its oracle (bf16: fp32 matmul rounded once,
+    /root/reference/test_gemm.py:15-21; fp8: oracle/gemm.py after /root/reference/test_gemm_fp8.py:32-45; int8: the exact-integer
+    evaluation of /root/reference/test_gemm_int8.py:41-47, bit for bit) and against the tile kernels (SGLK_DENSE_MID_MAX=1024)."""
+    M, N, K, has_bias = shape
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    x = (torch.randn(M, K, generator=g) / 8).bfloat16()
+    wb = (torch.randn(N, K, generator=g) / 8).bfloat16()
+    bias = torch.randn(N, generator=g) if has_bias else None
+    b = bias.cuda() if has_bias else None
+    ref_b = x.float() @ wb.float().t() + (bias if has_bias else 0)
+    inp = recipes.gemm_fp8_inputs(M, N, K, has_bias, False, 5300 + M)
+    ref_f = ogemm.fp8_scaled_mm(inp["data"], inp["w"], inp["scales"], (64, 128), inp["bias"] if has_bias else None)
+    Bq = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    Bs = torch.rand(N, generator=g) * 1e-2 + 1e-4
+    Aq, As = ogemm.per_token_quant_int8(x)
+    exact = As.float().view(-1, 1) * (Aq.double() @ Bq.double().t()).long().to(torch.float32) * Bs.view(1, -1)
+    exact = (exact + bias.view(1, -1) if has_bias else exact).bfloat16()
+    wbp, wfp, wip = (ops.convert_weight_packed(t.cuda()) for t in (wb, inp["w"], Bq))
+    fb = inp["bias"].cuda() if has_bias else None
+    outs = {}
+    for mx in (None, 1024):
+        knob(SGLK_DENSE_MID_MAX=mx, SGLK_DENSE_MID_WGS_BF16=100000 if mx is None else None,
+             SGLK_DENSE_MID_WGS_FP8=100000 if mx is None else None, SGLK_I8_DENSE_MID_WGS=100000 if mx is None else None)
+        ob = ops.weight_packed_linear(x.cuda(), wbp, b, True)
+        of = ops.fp8_scaled_mm_cpu(inp["data"].cuda(), wfp, inp["scales"].cuda(), [64, 128], fb, torch.bfloat16, True)
+        oi = ops.int8_scaled_mm_cpu(Aq.cuda(), wip, As.cuda(), Bs.cuda(), b, torch.bfloat16, True)
+        assert ref_pred(ref_b, ob) and rel_rms(ob, ref_b) < 3e-3, (shape, mx)
+        assert ref_pred(ref_f, of) and rel_rms(of, ref_f) < 4e-3, (shape, mx)
+        assert torch.equal(oi.cpu(), exact), (shape, mx)
+        outs[mx] = (ob, of)
+    assert rel_rms(outs[None][0], outs[1024][0].float().cpu()) < 3e-3
+    assert rel_rms(outs[None][1], outs[1024][1].float().cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("shape", [(192, 256, 128, False), (1000, 512, 1024, True), (300, 768, 2080, True), (2049, 1536, 2048, False)],
                          ids=lambda s: "x".join(map(str, s[:3])))
 def test_bf16_packed_linear_on_tuned_kernel(ops, shape):

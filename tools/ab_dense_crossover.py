@@ -17,7 +17,7 @@ for (N, K) in ((4096, 4096), (2048, 6144), (5120, 2048), (12288, 2048), (2048, 7
     sc = torch.rand(N // 128, K // 128, device="cuda", generator=g) * 1e-2
     wi = ops.convert_weight_packed(torch.randint(-127, 127, (N, K), device="cuda", generator=g, dtype=torch.int8))
     si = torch.rand(N, device="cuda", generator=g) * 1e-2
-    for M in (192, 256, 384, 512, 768, 1000):
+    for M in ((1024, 1280, 1536, 2000) if os.environ.get("PROBE_BIG") else (192, 256, 384, 512, 768, 1000)):
         x = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
         xq, xs = ops.per_token_quant_int8_cpu(x)
         row = {"N": N, "K": K, "M": M, "wgs256": -(-M // 256) * (N // 256)}

@@ -21,7 +21,7 @@ for (N, K) in ((2048, 7168), (768, 2048)):
     i2 = ops.convert_weight_packed(torch.randint(-127, 128, (K, N), device="cuda", generator=g, dtype=torch.int8))
     q1 = torch.rand(2 * N, device="cuda", generator=g) * 1e-3
     q2 = torch.rand(K, device="cuda", generator=g) * 1e-3
-    for M in (1, 16, 64, 128, 129, 160, 192, 256, 257, 384, 512, 768, 1000, 1024, 2048):
+    for M in ([1000, 1024, 1280, 1536, 2000, 2048] if os.environ.get("PROBE_BIG") else [1, 16, 64, 128, 129, 160, 192, 256, 257, 384, 512, 768, 1000, 1024, 2048]):
         hs = (torch.randn(M, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
         fo = torch.randn(M, K, device="cuda", generator=g).bfloat16()
         row = {"N": N, "K": K, "M": M}
