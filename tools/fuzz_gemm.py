@@ -60,7 +60,7 @@ def check(kind, desc, out, ref, rms_tol):
 for it in range(iters):
     kind = ("fp8", "int8", "bf16")[it % 3]
     count[kind] += 1
-    M = rng.choice([1, 3, 16, 17, 64, 100, 191, 192, 200, 256, 500, 777, 1000, 1023, 1024, 1025, 1500, 2048, 2300, 4096])
+    M = rng.choice([1, 3, 16, 17, 64, 100, 129, 160, 191, 192, 200, 256, 300, 500, 777, 1000, 1023, 1024, 1025, 1100, 1300, 1500, 1800, 2047, 2048, 2300, 4096])
     N = rng.choice([64, 128, 256, 320, 512, 576, 768, 1024, 1536, 2048, 2304, 4096])
     K = rng.choice([128, 256, 384, 512, 768, 1024, 2048, 2560, 4096, 6144, 7168])
     while M > 1 and 2.0 * M * N * K > 4e10:
