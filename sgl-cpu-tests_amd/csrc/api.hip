@@ -66,6 +66,7 @@ void read_env() {
     k.mxfp4_native = env_int("SGLK_MXFP4_NATIVE", -1);
     k.mxfp4_rt = env_int("SGLK_MXFP4_RT", 4);
     k.no_pack_on_the_fly = env_set("SGLK_NO_PACK_ON_THE_FLY");
+    k.pack_min_rows = env_int("SGLK_PACK_MIN_ROWS", 0);
     k.inline_align_max = env_int("SGLK_INLINE_ALIGN_MAX", 16);
     k.no_block_fold = env_set("SGLK_NO_BLOCK_FOLD");
     k.s128 = env_int("SGLK_S128", -1);

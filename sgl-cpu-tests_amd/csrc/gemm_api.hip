@@ -615,7 +615,17 @@ namespace sglk {
 // kernel beats the generic engine 3-4x (1000 x 18432 x 2560 int8: 0.32 -> 0.09 ms); decode sizes are bound by the weight bytes
 // and read them once either way.  Shapes sglk_pack_weight takes: bf16 rows % 32 / cols % 8, fp8 / int8 rows % 16 / cols % 64.
 static bool pack_on_the_fly(int M, int N, int K, int wtype, int packed) {
-    if (packed || M < 192 || knobs().force_generic || knobs().no_pack_on_the_fly) return false;
+    if (packed || knobs().force_generic || knobs().no_pack_on_the_fly) return false;
+    int min_rows = knobs().pack_min_rows;
+    if (min_rows <= 0) {
+        // Below 192 rows the re-tiling pass (one read + one write of the weight) still pays where the generic engine is far from
+        // reading the weight once: same-box A/B (tools/ab_pack_min_rows.py, profiles/r03_ab_pack_min_rows.txt), 191 x 4096 x 4096:
+        // fp8 53 -> 28 us, int8 with quantisation 68 -> 32, bf16 51 -> 37; crossover at 64 rows (fp8, int8) / 128 rows (bf16) for
+        // layers of >= 4 Mi elements, smaller bf16 / fp8 layers stay on the generic engine (512 x 1024: 11 vs 14 us)
+        const bool big = (int64_t)N * K >= (1ll << 22);
+        min_rows = wtype == SGLK_W_INT8 ? 64 : (!big ? 192 : (wtype == SGLK_W_BF16 ? 128 : 64));
+    }
+    if (M < min_rows) return false;
     if (wtype == SGLK_W_BF16) return N % 32 == 0 && K % 8 == 0;
     return (wtype == SGLK_W_FP8_E4M3 || wtype == SGLK_W_INT8) && N % 16 == 0 && K % 64 == 0;
 }

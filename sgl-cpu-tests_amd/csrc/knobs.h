@@ -39,6 +39,7 @@ struct Knobs {
     int attn_nw = 0;             // SGLK_ATTN_NW: waves per extend-attention workgroup (4 / 8); 0 = by launch size
     int attn_pair = -1;          // SGLK_ATTN_PAIR: heavy + light causal query blocks in one workgroup (0 / 1); unset = by launch size
     int attn_pp = -1;            // SGLK_ATTN_PP: 0 = one-phase extend kernel for D = DV = 128 too (A/B)
+    int pack_min_rows = 0;       // SGLK_PACK_MIN_ROWS: row-major dense weights are re-tiled into the workspace from this many rows on (below: generic engine); 0 = by weight type and layer size (gemm_api.hip: pack_on_the_fly), 192 = before
     int no_pack_on_the_fly = 0;  // SGLK_NO_PACK_ON_THE_FLY: row-major dense weights stay on the generic engine at every M (A/B)
     int mxfp4_rt = 4;            // SGLK_MXFP4_RT: 32-row tiles per wave of the fp4-MFMA kernel (4 / 2; A/B)
     int mxfp4_native = -1;       // SGLK_MXFP4_NATIVE: 1 / 0 = fp4-MFMA kernel for every legal shape / never; unset = by tile count
